@@ -1,0 +1,273 @@
+"""Bandpass registry and the filter-table packer for the MI355X likelihood engine.
+
+Host-side, one-off work: load a (wavelength, transmission) table, normalise it the
+way the reference does, and fold everything that does not depend on the walker into two per-sample constants
+``(a_k, W_k)`` so that the device evaluates the band-averaged blackbody luminosity density as
+
+    L_nu(filter; T, R) = R**2 * sum_k W_k / (exp(a_k / T) - 1)
+
+Reference behaviour mirrored here (``/root/reference/lightcurve_fitting``):
+
+* ``filters.py:117-168``  -- ``Filter`` identity: ``name``, ``names`` (aliases), ``char``, ``fnu``, ``m0``, ``M0``
+* ``filters.py:170-230``  -- ``read_curve``: A->nm, stable sort by wavelength, T/max(T), nu = c/lambda in THz,
+  photon-weighted normalisation ``T_norm_per_freq``; ``freq_eff``; ``dfreq`` (sign-flipped)
+* ``filters.py:288-310``  -- ``synthesize``: trapezoid over the (descending) frequency grid of
+  ``spectrum(nu*(1+z)) * T_norm_per_freq``
+* ``filters.py:369-445``  -- the registry ``all_filters`` / ``filtdict`` (names and aliases are API surface)
+* ``models.py:1101-1128`` -- ``c1``, ``c2`` and the Planck function with its optional cut-off frequency
+
+Nothing in this module evaluates a likelihood; the arithmetic on walkers happens only in the HIP kernels.
+"""
+import os
+from functools import total_ordering
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'bandpasses.npz')
+
+# physical constants, CODATA 2018 / IAU 2015 (exact SI definitions where they exist)
+_H = 6.62607015e-34  # J s
+_KB = 1.380649e-23  # J / K
+_C = 299792458.  # m / s
+_RSUN = 6.957e8  # m
+
+#: speed of light in Angstrom THz (``filters.py:11``)
+c = _C * 1e10 / 1e12
+#: h/k_B in kK / THz (``models.py:1101``)
+c1 = 0.0479924307336622
+#: 8 pi^2 h / c^2 in W Hz^-1 (1000 Rsun)^-2 THz^-3 (``models.py:1102``)
+c2 = 281739904251.4432
+
+_bank = None
+
+
+def _tables():
+    global _bank
+    if _bank is None:
+        _bank = np.load(_DATA)
+    return _bank
+
+
+def trapezoid_weights(x):
+    """Weights ``w`` with ``sum(w * y) == trapz(y, x)`` for any ``y`` (x may be descending or have repeats)."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.zeros_like(x)
+    if len(x) > 1:
+        dx = np.diff(x)
+        w[:-1] += 0.5 * dx
+        w[1:] += 0.5 * dx
+    return w
+
+
+@total_ordering
+class Filter:
+    """A broadband filter: identity, zero point and (lazily loaded) normalised transmission curve.
+
+    Attributes mirror the reference's ``Filter`` (``filters.py:36-168``) as far as the likelihood path and its
+    callers need them: ``name``, ``names``, ``char``, ``system``, ``offset``, ``fnu``, ``m0``, ``M0``,
+    ``filename``, ``angstrom``; curve properties ``wl`` (nm, ascending), ``T`` (peak 1), ``freq`` (THz, descending),
+    ``T_norm_per_freq``, ``freq_eff``, ``dfreq``, ``wl_eff``, ``dwl``.
+    """
+
+    order = None
+
+    def __init__(self, names, offset=0, system=None, fnu=3.631e-23, filename='', angstrom=False, italics=True):
+        if isinstance(names, list):
+            self.name = names[0]
+            self.names = names
+        else:
+            self.name = names
+            self.names = [names]
+        if len(self.name) == 1:
+            self.char = self.name
+        else:
+            shortest = min(self.names, key=len)  # first of the shortest aliases, like a stable sort by length
+            self.char = shortest if len(shortest) == 1 else 'x'
+        self.offset = offset
+        self.system = system
+        self.italics = italics
+        self.fnu = fnu
+        if fnu is None:
+            self.m0 = self.M0 = float('nan')
+        else:
+            self.m0 = 2.5 * np.log10(fnu)
+            self.M0 = self.m0 + 90.19
+        self.filename = filename
+        self.angstrom = angstrom
+        self._curve = None
+
+    # --- curve ------------------------------------------------------------
+    def read_curve(self, force=False):
+        """Load and normalise the transmission curve (``filters.py:170-230``).  No-op for table-less filters."""
+        if (self._curve is not None and not force) or not self.filename:
+            return
+        raw = _tables()['bandpass/' + self.filename]
+        wl = raw[:, 0] / 10. if self.angstrom else raw[:, 0].copy()  # -> nm
+        order = np.argsort(wl, kind='stable')
+        wl = wl[order]
+        trans = raw[order, 1] / np.max(raw[:, 1])
+        freq = (_C * 1e-3) / wl  # c / lambda with lambda in nm -> THz
+        tw = trapezoid_weights(freq)
+        t_per_freq = trans / freq
+        t_norm = t_per_freq / np.sum(tw * t_per_freq)
+        dfreq = np.sum(tw * trans)
+        freq_eff = np.sum(tw * trans * freq) / dfreq
+        tw_wl = trapezoid_weights(wl)
+        dwl = np.sum(tw_wl * trans)
+        wl_eff = np.sum(tw_wl * trans * wl) / dwl
+        self._curve = dict(wl=wl, T=trans, freq=freq, T_norm_per_freq=t_norm, tw=tw, freq_eff=freq_eff,
+                           dfreq=-dfreq, wl_eff=wl_eff, dwl=dwl)
+
+    def _get(self, key):
+        self.read_curve()
+        return None if self._curve is None else self._curve[key]
+
+    wl = property(lambda self: self._get('wl'))
+    T = property(lambda self: self._get('T'))
+    freq = property(lambda self: self._get('freq'))
+    T_norm_per_freq = property(lambda self: self._get('T_norm_per_freq'))
+    freq_eff = property(lambda self: self._get('freq_eff'))
+    dfreq = property(lambda self: self._get('dfreq'))
+    wl_eff = property(lambda self: self._get('wl_eff'))
+    dwl = property(lambda self: self._get('dwl'))
+
+    @property
+    def nsamples(self):
+        fr = self.freq
+        return 0 if fr is None else len(fr)
+
+    def planck_table(self, z=0., cutoff_freq=np.inf, drop_zeros=True):
+        """Per-sample constants ``(a_k, W_k)`` of the band integral for source redshift ``z``.
+
+        ``a_k = c1 nu_k (1+z)`` [kK] and ``W_k = c2 nu'_k^3 min(1, nu_cut/nu'_k) tw_k Tnorm_k`` with the trapezoid
+        weights ``tw_k`` of the descending frequency grid (``filters.py:308-310`` + ``models.py:1127-1128``).
+        Samples with ``W_k == 0`` (zero-transmission rows, zero-width steps) contribute exactly 0 to the sum and
+        are dropped unless ``drop_zeros`` is false.
+        """
+        if not self.filename:
+            raise ValueError(f'filter {self.name!r} has no transmission table')
+        nu = self.freq * (1. + z)
+        a = c1 * nu
+        w = c2 * nu ** 3 * np.minimum(1., cutoff_freq / nu) * self._get('tw') * self.T_norm_per_freq
+        if drop_zeros:
+            keep = w != 0.
+            a, w = a[keep], w[keep]
+        return np.ascontiguousarray(a), np.ascontiguousarray(w)
+
+    # --- identity ---------------------------------------------------------
+    def __str__(self):
+        return self.name
+
+    def __repr__(self):
+        return '<filter ' + self.name + '>'
+
+    def __eq__(self, other):
+        return isinstance(other, Filter) and self.name == other.name
+
+    def __lt__(self, other):
+        return isinstance(other, Filter) and Filter.order.index(self.name) < Filter.order.index(other.name)
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+def _mk(names, offset=0, system=None, fnu=3.631e-23, filename='', nm=False, italics=True):
+    return Filter(names, offset, system, fnu, filename, angstrom=bool(filename) and not nm, italics=italics)
+
+
+#: every recognised filter, bluest first (same names, aliases, zero points and tables as ``filters.py:369-440``)
+all_filters = [
+    _mk('FUV', 8, 'GALEX', filename='GALEX_GALEX.FUV.dat'),
+    _mk('NUV', 8, 'GALEX', filename='GALEX_GALEX.NUV.dat'),
+    _mk(['UVW2', 'uvw2', 'W2', '2', 'uw2'], 8, 'Swift', 7.379e-24, 'Swift_UVOT.UVW2.dat'),
+    _mk(['UVM2', 'uvm2', 'M2', 'M', 'um2'], 8, 'Swift', 7.656e-24, 'Swift_UVOT.UVM2.dat'),
+    _mk(['UVW1', 'uvw1', 'W1', '1', 'uw1'], 4, 'Swift', 9.036e-24, 'Swift_UVOT.UVW1.dat'),
+    _mk(['u', "u'", 'up', 'uprime'], 3, 'Gunn', filename='SLOAN_SDSS.u.dat'),
+    _mk(['U_S', 's', 'us'], 3, 'Swift', 1.419e-23, 'Swift_UVOT.U.dat'),
+    _mk('U', 3, 'Johnson', 1.790e-23, 'Generic_Johnson.U.dat'),
+    _mk('B', 2, 'Johnson', 4.063e-23, 'Generic_Johnson.B.dat'),
+    _mk(['B_S', 'b', 'bs'], 2, 'Swift', 4.093e-23, 'Swift_UVOT.B.dat'),
+    _mk(['g', "g'", 'gp', 'gprime', 'F475W'], 1, 'Gunn', filename='SLOAN_SDSS.g.dat'),
+    _mk('g-DECam', 1, 'DECam', filename='CTIO_DECam.g.dat'),
+    _mk(['c', 'cyan'], 1, 'ATLAS', filename='ATLAS_cyan.txt', nm=True),
+    _mk('V', 1, 'Johnson', 3.636e-23, 'Generic_Johnson.V.dat'),
+    _mk(['V_S', 'v', 'vs'], 1, 'Swift', 3.664e-23, 'Swift_UVOT.V.dat'),
+    _mk('Itagaki', 0, 'Itagaki', filename='KAF-1001E.asci', nm=True, italics=False),
+    _mk('white', 0, 'MOSFiT', filename='white.txt', nm=True, italics=False),
+    _mk(['unfilt.', '0', 'C', 'clear', 'pseudobolometric', 'griz', 'RGB', 'LRGB'], 0, 'MOSFiT',
+        filename='pseudobolometric.txt', nm=True, italics=False),
+    _mk('G', 0, 'Gaia', filename='GAIA_GAIA0.G.dat'),
+    _mk('Kepler', 0, 'Kepler', filename='Kepler_Kepler.K.dat', italics=False),
+    _mk('TESS', 0, 'TESS', filename='TESS_TESS.Red.dat', italics=False),
+    _mk(['DLT40', 'Open', 'Clear'], 0, 'DLT40', filename='QE_E2V_MBBBUV_Broadband.csv', nm=True, italics=False),
+    _mk('w', 0, 'Gunn', filename='PAN-STARRS_PS1.w.dat'),
+    _mk(['o', 'orange'], 0, 'ATLAS', filename='ATLAS_orange.txt', nm=True),
+    _mk(['r', "r'", 'rp', 'rprime', 'F625W'], 0, 'Gunn', filename='SLOAN_SDSS.r.dat'),
+    _mk('r-DECam', 0, 'DECam', filename='CTIO_DECam.r.dat'),
+    _mk(['R', 'Rc', 'R_s'], 0, 'Johnson', 3.064e-23, 'Generic_Cousins.R.dat'),
+    _mk(['i', "i'", 'ip', 'iprime', 'F775W'], -1, 'Gunn', filename='SLOAN_SDSS.i.dat'),
+    _mk('i-DECam', -1, 'DECam', filename='CTIO_DECam.i.dat'),
+    _mk(['I', 'Ic'], -1, 'Johnson', 2.416e-23, 'Generic_Cousins.I.dat'),
+    _mk(['z_s', 'zs'], -2, 'Gunn', filename='PAN-STARRS_PS1.z.dat'),
+    _mk(['z', "z'", 'zp', 'zprime'], -2, 'Gunn', filename='SLOAN_SDSS.z.dat'),
+    _mk('z-DECam', -2, 'DECam', filename='CTIO_DECam.z.dat'),
+    _mk('y', -3, 'Gunn', filename='PAN-STARRS_PS1.y.dat'),
+    _mk('y-DECam', -3, 'DECam', filename='CTIO_DECam.Y.dat'),
+    _mk('J', -2, 'UKIRT', 1.589e-23, 'Gemini_Flamingos2.J.dat'),
+    _mk('H', -3, 'UKIRT', 1.021e-23, 'Gemini_Flamingos2.H.dat'),
+    _mk(['K', 'Ks'], -4, 'UKIRT', 0.640e-23, 'Gemini_Flamingos2.Ks.dat'),
+    _mk('L', -4, 'UKIRT', 0.285e-23),
+] + [
+    _mk(name, 0, 'JWST NIRCam', filename=f'JWST_NIRCam.{name}.dat', italics=False)
+    for name in ('F070W', 'F090W', 'F115W', 'F150W', 'F182M', 'F200W', 'F250M', 'F277W', 'F300M', 'F335M', 'F356W',
+                 'F360M', 'F444W')
+] + [
+    _mk(name, 0, 'JWST MIRI', filename=f'JWST_MIRI.{name}.dat', italics=False)
+    for name in ('F560W', 'F770W', 'F1000W', 'F1130W', 'F1280W', 'F1500W', 'F1800W', 'F2100W', 'F2550W')
+] + [
+    _mk('pseudobolometric, curve_fit', italics=False),
+    _mk('pseudobolometric, MCMC', italics=False),
+    _mk('pseudobolometric, integration', italics=False),
+    _mk('bolometric, curve_fit', italics=False),
+    _mk('bolometric, MCMC', italics=False),
+    _mk(['unknown', '?'], 0, 'unknown', italics=False),
+]
+
+Filter.order = [f.name for f in all_filters]
+
+#: alias -> Filter (``filters.py:442-445``)
+filtdict = {}
+for _f in all_filters:
+    for _n in _f.names:
+        filtdict[_n] = _f
+
+
+def as_filter(f):
+    """Accept a ``Filter`` or any alias string."""
+    if isinstance(f, Filter):
+        return f
+    try:
+        return filtdict[str(f)]
+    except KeyError:
+        raise KeyError(f'unrecognised filter {f!r}') from None
+
+
+class PackedTables:
+    """Concatenated ``(a_k, W_k)`` tables for a list of distinct filters (CSR layout: ``off[i]:off[i+1]``)."""
+
+    def __init__(self, filters, z=0., cutoff_freq=np.inf, drop_zeros=True):
+        self.filters = [as_filter(f) for f in filters]
+        a_parts, w_parts, off = [], [], [0]
+        for f in self.filters:
+            a, w = f.planck_table(z, cutoff_freq, drop_zeros)
+            a_parts.append(a)
+            w_parts.append(w)
+            off.append(off[-1] + len(a))
+        self.a = np.concatenate(a_parts) if a_parts else np.zeros(0)
+        self.w = np.concatenate(w_parts) if w_parts else np.zeros(0)
+        self.off = np.asarray(off, dtype=np.int32)
+        self.z = z
+        self.cutoff_freq = cutoff_freq
+
+    def index(self, f):
+        return self.filters.index(as_filter(f))

@@ -1,0 +1,466 @@
+"""CPU oracle for the light-curve log-likelihood hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy restatement of the reference algorithm
+(``/root/reference/lightcurve_fitting/{models,filters,fitting}.py``, snapshot 2024-10-24).  It exists to CHECK
+the HIP engine; nothing in ``lightcurve_fitting_amd`` imports it.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may use it.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against golden vectors that
+``tools/refgen/make_golden.py`` produced by running the reference's own ``models.py``/``filters.py`` on the build
+host (under unit/table stand-ins for the absent astropy package), and against the known answers KA-1..KA-8 of
+SURVEY.md section 8c.  Third-party arithmetic that is NOT pinned: the ``extinction`` package (E(B-V) != 0) and
+emcee's RNG stream (the stretch move below follows emcee's published algorithm with its own counter-based RNG).
+
+Each function cites the reference lines it follows.
+"""
+import math
+
+import numpy as np
+from scipy.interpolate import CubicSpline  # the reference's spline is SciPy's (models.py:7, :717)
+
+# --- constants (CODATA 2018 / IAU 2015) -------------------------------------------------
+K_B = 0.08617333262145178  # eV / kK                                   models.py:10
+C3 = 5.38477047522316e-19  # (4 pi sigma_SB)^-1/2 in kiloRsun units     models.py:11
+C4 = 8.357743635931361e-47  # 1 / (4 pi Mpc^2)                          models.py:12
+C1 = 0.0479924307336622  # h / k_B, kK / THz                            models.py:1101
+C2 = 281739904251.4432  # 8 pi^2 h / c^2, W Hz^-1 kiloRsun^-2 THz^-3    models.py:1102
+C_NM_THZ = 299792.458  # c in nm THz                                    filters.py:189
+SIGMA_SB = 2.744452656619892e+28  # W kiloRsun^-2 kK^-4                 bolometric.py:419
+
+if hasattr(np, 'trapezoid'):
+    _trapz = np.trapezoid
+else:  # NumPy < 2
+    _trapz = np.trapz
+
+
+def pw(base, exp):
+    """``base ** exp`` where ``base > 0``, else 0 (also for NaN bases).  models.py:42-48"""
+    base = np.asarray(base, dtype=np.float64)
+    shape = np.broadcast(base, exp).shape
+    out = np.zeros(shape, dtype=np.float64)
+    ok = np.broadcast_to(base > 0., shape)
+    with np.errstate(all='ignore'):
+        np.power(base, exp, out=out, where=ok)
+    return out
+
+
+# --- bandpasses ----------------------------------------------------------------------------------------------
+class Band:
+    """Normalised transmission curve of one filter.  filters.py:170-230"""
+
+    def __init__(self, name, char, raw, angstrom):
+        self.name = name
+        self.char = char
+        wl = np.array(raw[:, 0], dtype=np.float64)
+        if angstrom:  # filters.py:184-185
+            wl = wl / 10.
+        order = np.argsort(wl, kind='stable')  # filters.py:187
+        wl = wl[order]
+        tr = raw[order, 1] / np.max(raw[:, 1])  # filters.py:188
+        self.wl = wl
+        self.T = tr
+        self.freq = C_NM_THZ / wl  # filters.py:189 (descending)
+        dfreq = _trapz(tr, self.freq)  # filters.py:209
+        self.freq_eff = _trapz(tr * self.freq, self.freq) / dfreq  # filters.py:210-211
+        self.dfreq = -dfreq  # filters.py:229
+        t_per_freq = tr / self.freq  # filters.py:213
+        self.tnorm = t_per_freq / _trapz(t_per_freq, self.freq)  # filters.py:214
+
+    def __repr__(self):
+        return f'<Band {self.name}>'
+
+    def __hash__(self):
+        return hash(self.name)
+
+    def __eq__(self, other):
+        return isinstance(other, Band) and other.name == self.name
+
+
+_BANDS = {}
+
+
+def band(name):
+    """Look a band up by any alias.  Only the *metadata* (file name, unit flag, aliases) comes from the package's
+    registry; the curve processing is this module's own (and is pinned by the golden vectors)."""
+    from lightcurve_fitting_amd import filters as _reg  # metadata only
+    f = _reg.as_filter(name)
+    if f.name not in _BANDS:
+        raw = np.load(_reg._DATA)['bandpass/' + f.filename]
+        _BANDS[f.name] = Band(f.name, f.char, raw, f.angstrom)
+    return _BANDS[f.name]
+
+
+def planck(nu, T, R, cutoff_freq=np.inf):
+    """Planck L_nu for frequency vector ``nu`` (THz), T (kK), R (kiloRsun).  models.py:1105-1128
+
+    ``T`` and ``R`` may have any common shape; the result has shape ``T.shape + nu.shape``."""
+    nu = np.asarray(nu, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    R = np.asarray(R, dtype=np.float64)
+    with np.errstate(all='ignore'):
+        prefac = np.multiply.outer(R ** 2, nu ** 3 * np.minimum(1., cutoff_freq / nu))
+        occupation = pw(np.exp(C1 * np.multiply.outer(pw(T, -1.), nu)) - 1., -1.)
+        return C2 * prefac * occupation
+
+
+def synthesize_blackbody(b, T, R, z=0., cutoff_freq=np.inf):
+    """Band-averaged L_nu of a blackbody.  filters.py:288-310 with ebv = 0 (extinction factor exactly 1)."""
+    freq = b.freq * (1. + z)
+    return _trapz(planck(freq, T, R, cutoff_freq) * b.tnorm, b.freq)
+
+
+def blackbody_to_filters_pointwise(bands, T, R, z=0., cutoff_freq=np.inf):
+    """Reference-shaped pointwise branch: one Python-level band integral per data point.  models.py:1161-1162"""
+    return np.array([synthesize_blackbody(b, t, r, z, cutoff_freq) for b, t, r in zip(bands, T, R)])
+
+
+def blackbody_to_filters_batch(bands, T, R, z=0., cutoff_freq=np.inf):
+    """Same numbers as the pointwise branch for ``T, R`` of shape (npoints, ...): grouped by band so that each band
+    is integrated for all of its points (and all walkers) at once."""
+    T = np.asarray(T, dtype=np.float64)
+    R = np.asarray(R, dtype=np.float64)
+    out = np.empty(T.shape, dtype=np.float64)
+    names = np.array([b.name for b in bands])
+    for nm in dict.fromkeys(names.tolist()):
+        sel = np.nonzero(names == nm)[0]
+        out[sel] = synthesize_blackbody(band(nm), T[sel], R[sel], z, cutoff_freq)
+    return out
+
+
+# --- shock cooling (Sapir & Waxman / Rabinak & Waxman) ---------------------------------------------------------
+class ShockCoolingOracle:
+    """models.py:139-353 (ShockCooling), :356-411 (ShockCooling2)."""
+
+    def __init__(self, z=0., n=1.5, RW=False):
+        self.z = z
+        if n == 1.5:  # models.py:194-203
+            self.A, self.a, self.alpha, self.eps1, self.eps2 = 0.94, 1.67, 0.8, 0.027, 0.086
+            self.L0, self.T0, self.ratio = 2.0e42, 1.61, 1.1
+        elif n == 3.:  # models.py:204-213
+            self.A, self.a, self.alpha, self.eps1, self.eps2 = 0.79, 4.57, 0.73, 0.016, 0.175
+            self.L0, self.T0, self.ratio = 2.1e42, 1.69, 1.0
+        else:
+            raise ValueError('n can only be 1.5 or 3')
+        self.n = n
+        self.eps_T = 2 * self.eps1 - 0.5  # models.py:217
+        self.eps_L = -2 * self.eps2  # models.py:218
+        self.RW = bool(RW)
+        if RW:  # models.py:219-222
+            self.a = 0.
+            self.ratio = 1.2
+
+    def temperature_radius(self, t_in, v_s, M_env, f_rho_M, R, t_exp=0., kappa=1.):
+        """models.py:260-269.  Parameters may be scalars or (nwalkers,) arrays -> outputs (npoints[, nwalkers])."""
+        with np.errstate(all='ignore'):
+            t = np.reshape(t_in, (-1, 1)) - t_exp
+            L_RW = self.L0 * pw(t ** 2 * v_s / (f_rho_M * kappa), -self.eps2) * v_s ** 2 * R / kappa
+            t_tr = 19.5 * (kappa * M_env / v_s) ** 0.5
+            L = L_RW * self.A * np.exp(-pw(self.a * t / t_tr, self.alpha))
+            T_ph = self.T0 * pw(t ** 2 * v_s ** 2 / (f_rho_M * kappa), self.eps1) * kappa ** -0.25 \
+                * pw(t, -0.5) * R ** 0.25
+            T_K = np.squeeze(T_ph * self.ratio) / K_B
+            R_bb = C3 * np.squeeze(L) ** 0.5 * pw(T_K, -2.)
+        return T_K, R_bb
+
+    def temperature_radius2(self, t_in, T_1, L_1, t_tr, t_exp=0.):
+        """ShockCooling2 scaling form.  models.py:403-406"""
+        with np.errstate(all='ignore'):
+            t = np.reshape(t_in, (-1, 1)) - t_exp
+            T_K = np.squeeze(T_1 * pw(t, self.eps_T))
+            L = np.squeeze(L_1 * np.exp(-pw(self.a * t / t_tr, self.alpha)) * pw(t, self.eps_L)) * 1e42
+            R_bb = C3 * L ** 0.5 * pw(T_K, -2.)
+        return T_K, R_bb
+
+
+class ShockCooling4Oracle:
+    """Morag, Sapir & Waxman form, with the reference's quirks kept.  models.py:507-632"""
+
+    def __init__(self, z=0.):
+        self.z = z
+        self.A, self.a, self.alpha = 0.9, 2., 0.5
+        self.L_br_0, self.T_col_br_0, self.t_br_0, self.t_tr_0 = 3.69e42, 8.19, 0.036, 19.5
+
+    def temperature_radius(self, t_in, v_s, M_env, f_rho_M, R, t_exp=0., kappa=1.):
+        with np.errstate(all='ignore'):
+            t_br = self.t_br_0 * R ** 1.26 * v_s ** -1.13 * f_rho_M ** -0.13  # models.py:584 (no kappa)
+            L_br = self.L_br_0 * R ** 0.78 * v_s ** 2.11 * f_rho_M ** 0.11 * kappa ** -0.89  # :585
+            # :586 -- Python's ** is right-associative: v_s ** (0.58 ** (f_rho_M ** 0.03))
+            T_col_br = self.T_col_br_0 * R ** -0.32 * v_s ** (0.58 ** (f_rho_M ** 0.03)) * kappa ** -0.22
+            t_tr = self.t_tr_0 * np.sqrt(kappa * M_env / v_s)  # :587
+            t = np.reshape(t_in, (-1, 1)) - t_exp
+            tt = t / t_br
+            L = L_br * (pw(tt, -4. / 3.) + self.A * np.exp(-pw(self.a * t / t_tr, self.alpha)) * pw(tt, -0.17))
+            T_col = T_col_br * np.minimum(0.97 * pw(tt, -1. / 3.), pw(tt, -0.45))  # :594
+            T_K = np.squeeze(T_col) / K_B
+            R_bb = C3 * np.squeeze(L) ** 0.5 * pw(T_K, -2.)
+        return T_K, R_bb
+
+
+# --- companion shocking (Kasen) + SiFTO template --------------------------------------------------------------
+def kasen_temperature_radius(t_in, t_exp, a13, Mc_v9_7, kappa=1.):
+    """models.py:752-755"""
+    with np.errstate(all='ignore'):
+        t = np.reshape(t_in, (-1, 1)) - t_exp
+        T = np.squeeze(25. * pw(a13 ** 36. * Mc_v9_7 * kappa ** -35. * pw(t, -74.), 1. / 144.))
+        R = np.squeeze(2.7 * pw(kappa * Mc_v9_7 * t ** 7., 1. / 9.))
+    return T, R
+
+
+_SIFTO_COLS = ('Epoch', 'U', 'B', 'V', 'g', 'r', 'i')
+
+
+def sifto_table():
+    """Template rows 3.. (the first three are ~0).  models.py:660-661"""
+    from lightcurve_fitting_amd import filters as _reg  # data file location only
+    return np.load(_reg._DATA)['template/sifto'][3:]
+
+
+class CompanionShockingOracle:
+    """models.py:665-1045.  ``variant`` 1, 2 or 3 selects CompanionShocking{,2,3}."""
+
+    def __init__(self, bands, lum, z=0., variant=1):
+        self.z = z
+        self.variant = variant
+        tab = sifto_table()
+        epoch = tab[:, 0]
+        names = [b.name for b in bands]
+        lum = np.asarray(lum, dtype=np.float64)
+        self.splines = {}
+        for nm in dict.fromkeys(names):  # models.py:701-717
+            b = band(nm)
+            if nm == 'unfilt.' and 'DLT40' in names:
+                col, scale_by = 'r', 'DLT40'
+            elif nm == 'DLT40':
+                col, scale_by = 'r', nm
+            elif b.char in _SIFTO_COLS[1:]:
+                col, scale_by = b.char, nm
+            else:
+                raise Exception('No SiFTO template for filter ' + nm)
+            column = tab[:, _SIFTO_COLS.index(col)]
+            peak = np.max(lum[[x == scale_by for x in names]])
+            self.splines[nm] = CubicSpline(epoch, column * peak / np.max(column), extrapolate=False)
+
+    def stretched_sifto(self, t_in, bands, t_peak, stretch, dtU=None, dti=None):
+        """Pointwise branch, scalar parameters.  models.py:808-827"""
+        out = np.empty(len(bands))
+        for i, (t, b) in enumerate(zip(np.asarray(t_in, dtype=np.float64) - t_peak, bands)):
+            dt = 0.
+            if b.name == 'U' and dtU is not None:
+                dt = dtU
+            elif b.name == 'i' and dti is not None:
+                dt = dti
+            out[i] = self.splines[b.name]((t - dt) / stretch)
+        out[np.isnan(out)] = 0.
+        return out
+
+    def evaluate(self, t_in, bands, *p):
+        if self.variant == 1:  # models.py:909-917
+            t_exp, a13, Mv, t_peak, s, rr, ri, rU = p
+            T, R = kasen_temperature_radius(t_in, t_exp, a13, Mv)
+            kas = blackbody_to_filters_batch(bands, T, R, self.z)
+            sif = self.stretched_sifto(t_in, bands, t_peak, s)
+            kf = np.array([rU if b.char == 'U' else 1. for b in bands])
+            sf = np.array([rr if b.char == 'r' else ri if b.char == 'i' else 1. for b in bands])
+            return kas * kf + sif * sf
+        if self.variant == 2:  # models.py:977-980
+            t_exp, a13, Mv, t_peak, s, dtU, dti = p
+            T, R = kasen_temperature_radius(t_in, t_exp, a13, Mv)
+            return blackbody_to_filters_batch(bands, T, R, self.z) + self.stretched_sifto(t_in, bands, t_peak, s,
+                                                                                        dtU, dti)
+        t_exp, a13, theta, t_peak, s, dtU, dti = p  # models.py:1040-1045
+        T, R = kasen_temperature_radius(t_in, t_exp, a13, 1.)
+        th = np.deg2rad(theta)
+        frac = (0.5 * np.cos(th) + 0.5) * (0.14 * th ** 2. - 0.4 * th + 1.)
+        return blackbody_to_filters_batch(bands, T, R, self.z) * frac + self.stretched_sifto(t_in, bands, t_peak, s,
+                                                                                           dtU, dti)
+
+
+# --- model evaluation front ends -------------------------------------------------------------------------------
+def evaluate(model, t, bands, p, reference_shaped=False):
+    """``y_fit`` [npoints] for one parameter vector, or [npoints, nwalkers] for ``p`` of shape (nparams, nwalkers).
+
+    ``model`` is ``('ShockCooling', oracle)``, ``('ShockCooling2', oracle)``, ``('ShockCooling4', oracle)`` or
+    ``('CompanionShocking', oracle)``.  ``reference_shaped`` uses the per-point Python loop (models.py:1161-1162)."""
+    kind, orc = model
+    p = [np.asarray(x, dtype=np.float64) for x in p]
+    bb = blackbody_to_filters_pointwise if reference_shaped else blackbody_to_filters_batch
+    if kind == 'ShockCooling':  # models.py:351-353
+        T, R = orc.temperature_radius(t, *p)
+        return bb(bands, T, R, orc.z)
+    if kind == 'ShockCooling2':  # models.py:403-407
+        T, R = orc.temperature_radius2(t, *p)
+        return bb(bands, T, R, orc.z)
+    if kind == 'ShockCooling4':  # models.py:628-632
+        T, R = orc.temperature_radius(t, *p)
+        return np.minimum(bb(bands, T, R, orc.z), bb(bands, 0.74 * T, 0.74 ** -2. * R, orc.z))
+    if kind == 'CompanionShocking':
+        return orc.evaluate(t, bands, *[float(x) for x in p])
+    if kind == 'Blackbody':  # bolometric.py:154-164: p = (T, R) are direct parameters
+        T = np.broadcast_to(p[0], (len(bands),) + p[0].shape)
+        R = np.broadcast_to(p[1], (len(bands),) + p[1].shape)
+        return bb(bands, T, R, orc.z)
+    raise ValueError(kind)
+
+
+def log_likelihood(model, t, bands, y, dy, p, use_sigma=False, sigma_type='relative', reference_shaped=False):
+    """Gaussian log-likelihood incl. the normalisation term.  models.py:116-136
+
+    ``p``: (ndim,) -> float, or (ndim, nwalkers) -> (nwalkers,)."""
+    y = np.asarray(y, dtype=np.float64)
+    dy = np.asarray(dy, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    if sigma_type == 'relative':
+        units = dy
+    elif sigma_type == 'absolute':
+        units = np.median(dy)
+    else:
+        raise Exception('sigma_type must either be "relative" or "absolute"')
+    batched = p.ndim == 2
+    if use_sigma:
+        y_fit = evaluate(model, t, bands, p[:-1], reference_shaped)
+        if batched:
+            sigma = np.sqrt(dy[:, None] ** 2. + np.multiply.outer(units, p[-1]) ** 2.)
+        else:
+            sigma = np.sqrt(dy ** 2. + (p[-1] * units) ** 2.)
+    else:
+        y_fit = evaluate(model, t, bands, p, reference_shaped)
+        sigma = dy[:, None] if batched else dy
+    resid = (y[:, None] - y_fit) if batched else (y - y_fit)
+    with np.errstate(all='ignore'):
+        return -0.5 * np.sum(np.log(2 * np.pi * sigma ** 2.) + (resid / sigma) ** 2., axis=0)
+
+
+# --- priors and posterior ------------------------------------------------------------------------------------
+PRIOR_UNIFORM, PRIOR_LOGUNIFORM, PRIOR_GAUSSIAN = 0, 1, 2
+
+
+def log_prior(priors, p):
+    """``priors``: sequence of (kind, p_min, p_max, mean, stddev).  models.py:1048-1098; strict bounds."""
+    total = 0.
+    for (kind, lo, hi, mean, std), x in zip(priors, p):
+        if not (lo < x < hi):
+            return -np.inf
+        if kind == PRIOR_LOGUNIFORM:
+            total += -np.log(x)
+        elif kind == PRIOR_GAUSSIAN:
+            total += -0.5 * ((x - mean) / std) ** 2.
+    return total
+
+
+def log_posterior(model, t, bands, y, dy, priors, p, use_sigma=False, sigma_type='relative'):
+    """fitting.py:121-128: prior first; the likelihood is not evaluated when the prior is -inf."""
+    lp = log_prior(priors, p)
+    if np.isinf(lp):
+        return lp
+    return lp + log_likelihood(model, t, bands, y, dy, p, use_sigma, sigma_type)
+
+
+# --- bolometric helpers ----------------------------------------------------------------
+def pseudo(temp, radius, z, band0=None, band1=None, cutoff_freq=np.inf):
+    """1-THz-grid trapezoid of the Planck function between two bands.  bolometric.py:32-59"""
+    band0 = band0 or band('I')
+    band1 = band1 or band('U')
+    freq0 = band0.freq_eff - band0.dfreq / 2.
+    freq1 = band1.freq_eff + band1.dfreq / 2.
+    x = np.arange(freq0, freq1)
+    return _trapz(planck(x * (1. + z), temp, radius, cutoff_freq)) * 1e12
+
+
+def stefan_boltzmann(temp, radius):
+    """bolometric.py:449"""
+    return 4 * np.pi * radius ** 2 * SIGMA_SB * temp ** 4
+
+
+def mag2flux(mag, dmag, zp):
+    """lightcurve.py:936-937 (detections only)"""
+    flux = 10 ** ((zp - mag) / 2.5)
+    return flux, np.log(10) / 2.5 * flux * dmag
+
+
+# --- counter-based RNG (Philox4x32-10) and the stretch move -----------------------------------------------------
+_PH_M0, _PH_M1 = 0xD2511F53, 0xCD9E8D57
+_PH_W0, _PH_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32(counter, key):
+    """Philox4x32-10 (Salmon et al. 2011).  ``counter``: 4 uint32 words (array-like broadcastable), ``key``: 2 words.
+    Returns a tuple of four uint32 arrays."""
+    c = [np.asarray(x, dtype=np.uint64) for x in counter]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(_PH_M0) * c[0]
+        p1 = np.uint64(_PH_M1) * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c = [(hi1 ^ c[1] ^ k0) & mask, lo1, (hi0 ^ c[3] ^ k1) & mask, lo0]
+        k0 = (k0 + np.uint64(_PH_W0)) & mask
+        k1 = (k1 + np.uint64(_PH_W1)) & mask
+    return tuple(x.astype(np.uint32) for x in c)
+
+
+def u01(hi, lo):
+    """53-bit uniform in (0, 1) from two uint32 words: ((hi << 21) ^ (lo >> 11) + 0.5) * 2^-53."""
+    v = (np.asarray(hi, dtype=np.uint64) << np.uint64(21)) ^ (np.asarray(lo, dtype=np.uint64) >> np.uint64(11))
+    return (v.astype(np.float64) + 0.5) * (1. / 9007199254740992.)
+
+
+def stretch_draws(seed, step, half, walker_ids, n_other, a=2.):
+    """Random numbers of one half-step for the listed active walkers: stretch factor z, partner index j (into the
+    complementary set, ``n_other`` long) and ln(u) for the acceptance test.  Keyed by (seed, step, half, walker) so
+    that the stream does not depend on how walkers are sharded over devices."""
+    wid = np.asarray(walker_ids, dtype=np.uint64)
+    r0, r1, r2, r3 = philox4x32((wid, np.full_like(wid, step), np.full_like(wid, half), np.zeros_like(wid)),
+                                (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    s0, s1, _, _ = philox4x32((wid, np.full_like(wid, step), np.full_like(wid, half), np.ones_like(wid)),
+                              (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    z = ((a - 1.) * u01(r0, r1) + 1.) ** 2. / a
+    j = (u01(r2, r3) * n_other).astype(np.int64)
+    j = np.minimum(j, n_other - 1)
+    ln_u = np.log(u01(s0, s1))
+    return z, j, ln_u
+
+
+def split_permutation(seed, step, nwalkers):
+    """Random red/blue colouring of a step (emcee's ``randomize_split``): a permutation of walker ids whose first
+    half is colour 0.  Walkers are ranked by a Philox key; ties (probability ~2^-64) break by walker id."""
+    wid = np.arange(nwalkers, dtype=np.uint64)
+    r0, r1, _, _ = philox4x32((wid, np.full_like(wid, step), np.full_like(wid, 2), np.full_like(wid, 7)),
+                              (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    keys = (r0.astype(np.uint64) << np.uint64(32)) | r1.astype(np.uint64)
+    return np.lexsort((wid, keys))
+
+
+def stretch_move_run(log_prob_fn, coords, nsteps, seed, a=2., log_prob0=None, randomize_split=True, first_step=0):
+    """Affine-invariant ensemble sampler with the stretch move and a red/blue split (Goodman & Weare 2010;
+    emcee 3.x ``StretchMove``/``RedBlueMove`` semantics).
+
+    ``log_prob_fn`` maps an (n, ndim) block to (n,) log-probabilities.  Returns (chain[nsteps, nw, ndim],
+    log_prob[nsteps, nw], accepted[nw])."""
+    x = np.array(coords, dtype=np.float64)
+    nw, ndim = x.shape
+    lp = np.array(log_prob_fn(x) if log_prob0 is None else log_prob0, dtype=np.float64)
+    chain = np.empty((nsteps, nw, ndim))
+    lps = np.empty((nsteps, nw))
+    nacc = np.zeros(nw, dtype=np.int64)
+    half_n = nw // 2
+    for it in range(nsteps):
+        step = first_step + it
+        perm = split_permutation(seed, step, nw) if randomize_split else np.arange(nw)
+        sets = (perm[:half_n], perm[half_n:])
+        for half in (0, 1):
+            act, oth = sets[half], sets[1 - half]
+            z, j, ln_u = stretch_draws(seed, step, half, act, len(oth), a)
+            partner = x[oth[j]]
+            q = partner - (partner - x[act]) * z[:, None]
+            new_lp = np.asarray(log_prob_fn(q), dtype=np.float64)
+            if np.any(np.isnan(new_lp)):
+                raise ValueError('Probability function returned NaN')
+            with np.errstate(invalid='ignore'):
+                ok = (ndim - 1.) * np.log(z) + new_lp - lp[act] > ln_u
+            x[act[ok]] = q[ok]
+            lp[act[ok]] = new_lp[ok]
+            nacc[act[ok]] += 1
+        chain[it] = x
+        lps[it] = lp
+    return chain, lps, nacc
