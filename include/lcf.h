@@ -1,0 +1,183 @@
+/*
+ * lcf.h -- C ABI of the MI355X (gfx950) batched light-curve log-likelihood engine.
+ *
+ * This is the drop-in boundary for the emcee-driven hot path of griffin-h/lightcurve_fitting.  The reference has no
+ * native code: the seam is the Python callable that `fitting.lightcurve_mcmc` hands to `emcee.EnsembleSampler`
+ * (reference fitting.py:121-130).  Each entry point below names the reference interface it replaces.  All arrays are
+ * caller-owned; the engine copies photometry and tables to the device at create time and never writes to caller
+ * memory except the documented outputs.  No exceptions cross this boundary: every call returns an lcf_status.
+ *
+ * Shapes: a "walker block" P is row-major (n x n_dim) float64, exactly what emcee passes to a `vectorize=True`
+ * log-probability function.  Units follow the reference (days, kK, 1000 Rsun, THz, W/Hz).
+ *
+ * Thread-safety: calls on one engine (or one sampler) must be serialised by the caller; distinct engines are
+ * independent.  One engine is bound to one HIP device.
+ */
+#ifndef LCF_H
+#define LCF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCF_ABI_VERSION 1
+
+typedef enum lcf_status {
+    LCF_OK = 0,
+    LCF_ERR_INVALID_ARGUMENT = 1, /* NULL pointer, bad size, unknown model, inconsistent tables */
+    LCF_ERR_HIP = 2,              /* a HIP runtime call failed; see lcf_last_error() */
+    LCF_ERR_NO_DEVICE = 3,        /* no usable GPU: this library has no CPU fallback */
+    LCF_ERR_OUT_OF_MEMORY = 4,
+    LCF_ERR_UNSUPPORTED = 5,      /* e.g. ShockCooling3 (needs third-party extinction arithmetic) */
+    LCF_ERR_NAN_LOGPROB = 6,      /* sampler: a log-probability evaluated to NaN (emcee raises ValueError here) */
+    LCF_ERR_STATE = 7             /* call sequence error (e.g. run before set_state) */
+} lcf_status;
+
+/* Model families (reference models.py).  Values are stable ABI. */
+typedef enum lcf_model {
+    LCF_MODEL_SHOCK_COOLING = 1,      /* ShockCooling          models.py:301-353  p = v_s, M_env, f_rho_M, R, t_0     */
+    LCF_MODEL_SHOCK_COOLING2 = 2,     /* ShockCooling2         models.py:356-411  p = T_1, L_1, t_tr, t_0             */
+    LCF_MODEL_SHOCK_COOLING4 = 4,     /* ShockCooling4         models.py:507-632  p = v_s, M_env, f_rho_M, R, t_0     */
+    LCF_MODEL_COMPANION_SHOCKING = 5, /* CompanionShocking     models.py:848-918  p = t_0,a,Mv7,t_max,s,r_r,r_i,r_U   */
+    LCF_MODEL_COMPANION_SHOCKING2 = 6,/* CompanionShocking2    models.py:921-980  p = t_0,a,Mv7,t_max,s,dt_U,dt_i     */
+    LCF_MODEL_COMPANION_SHOCKING3 = 7,/* CompanionShocking3    models.py:983-1045 p = t_0,a,theta,t_max,s,dt_U,dt_i   */
+    LCF_MODEL_BLACKBODY = 8           /* direct (T, R) blackbody, bolometric.py:154-164                              */
+} lcf_model;
+
+/* Priors (reference models.py:1048-1098).  Bounds are strict: p_min < p < p_max, else log-prior = -inf. */
+typedef enum lcf_prior_kind { LCF_PRIOR_UNIFORM = 0, LCF_PRIOR_LOG_UNIFORM = 1, LCF_PRIOR_GAUSSIAN = 2 } lcf_prior_kind;
+
+typedef struct lcf_prior {
+    int32_t kind; /* lcf_prior_kind */
+    int32_t reserved;
+    double p_min, p_max;
+    double mean, stddev; /* Gaussian only */
+} lcf_prior;
+
+enum { LCF_SIGMA_RELATIVE = 0, LCF_SIGMA_ABSOLUTE = 1 };
+enum { LCF_N_CONSTS = 12 };
+
+/*
+ * One fitting problem = one light curve + one model instance (with its construction-time constants baked in).
+ *
+ * consts[] by model:
+ *   SHOCK_COOLING, SHOCK_COOLING2: A, a, alpha, epsilon_1, epsilon_2, L_0, T_0, Tph_to_Tcol  (models.py:192-226)
+ *   SHOCK_COOLING4:                A, a, alpha, L_br_0, T_col_br_0, t_br_0, t_tr_0           (models.py:567-577)
+ *   others:                        unused
+ *
+ * Band tables: filter i owns samples tab_off[i] .. tab_off[i+1]-1 of (tab_a, tab_w) with
+ *   a_k = c1 nu_k (1+z)  [kK],   W_k = c2 nu'_k^3 min(1, nu_cut/nu'_k) tw_k Tnorm_k,
+ * so that L_nu(filter; T, R) = R^2 sum_k W_k / (exp(a_k/T) - 1)   (filters.py:308-310 + models.py:1127-1128).
+ *
+ * Companion-shocking extras (NULL / 0 otherwise): per-filter parameter indices (or -1) for the factor on the shock
+ * term, the factor on the SiFTO term and the SiFTO time offset (models.py:804-807, 913-916), and one piecewise-cubic
+ * per filter: spline_coef[f][i][0..3] are the coefficients of (x - knot_i)^3..^0 on [knot_i, knot_i+1]; the
+ * template is 0 outside [knot_0, knot_{n-1}] (models.py:717, 826).
+ */
+typedef struct lcf_problem {
+    int32_t abi_version; /* LCF_ABI_VERSION */
+    int32_t model;       /* lcf_model */
+    int32_t n_par;       /* model parameters (without the optional intrinsic-scatter parameter) */
+    int32_t use_sigma;   /* 1: the last of n_dim = n_par + 1 parameters is sigma (models.py:128-130) */
+    int32_t sigma_type;  /* LCF_SIGMA_RELATIVE | LCF_SIGMA_ABSOLUTE (models.py:121-126) */
+    int32_t n_filters;
+    int64_t n_points;
+    double consts[LCF_N_CONSTS];
+    const double* t;          /* [n_points] observation times (lc['MJD'])                     models.py:117 */
+    const double* y;          /* [n_points] observed luminosity density (lc['lum'])           models.py:118 */
+    const double* dy;         /* [n_points] its uncertainty (lc['dlum'])                      models.py:119 */
+    const int32_t* filt_idx;  /* [n_points] filter of each point, 0 <= . < n_filters          models.py:116 */
+    const int32_t* tab_off;   /* [n_filters + 1] */
+    const double* tab_a;      /* [tab_off[n_filters]] */
+    const double* tab_w;      /* [tab_off[n_filters]] */
+    const int32_t* filt_kasen_par; /* [n_filters] or NULL */
+    const int32_t* filt_sifto_par; /* [n_filters] or NULL */
+    const int32_t* filt_dt_par;    /* [n_filters] or NULL */
+    int32_t n_knots;
+    int32_t reserved;
+    const double* spline_knots;    /* [n_knots] ascending */
+    const double* spline_coef;     /* [n_filters][n_knots - 1][4] */
+    const lcf_prior* priors;       /* [n_par + use_sigma] or NULL (then log_posterior == log_likelihood) */
+} lcf_problem;
+
+typedef struct lcf_engine lcf_engine;
+typedef struct lcf_sampler lcf_sampler;
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int32_t lcf_abi_version(void);
+/* Human-readable description of the last failure on the calling thread ("" if none). */
+const char* lcf_last_error(void);
+/* Number of HIP devices visible (0 if none / no driver).  Never initialises a context on a device. */
+int32_t lcf_device_count(void);
+
+/* ---- engine --------------------------------------------------------------------------------------------------- */
+/* Replaces the closure set-up of fitting.py:68-128 (photometry columns + model + priors captured once). */
+lcf_status lcf_engine_create(const lcf_problem* problem, int32_t device, lcf_engine** out);
+void lcf_engine_destroy(lcf_engine* e);
+int32_t lcf_engine_ndim(const lcf_engine* e);
+int64_t lcf_engine_npoints(const lcf_engine* e);
+/* Planck samples one log-likelihood evaluation sums (after dropping nothing): sum over points of K_filter. */
+int64_t lcf_engine_samples_per_eval(const lcf_engine* e);
+/* Select the band-sum variant: 0 = libm expm1 + divide (reference-shaped), 1 = fused fast path (default). */
+lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant);
+
+/* Model.log_likelihood (models.py:93-136) for a block of n walkers.  Host pointers. out[n]. */
+lcf_status lcf_log_likelihood(lcf_engine* e, int64_t n, const double* P, double* out);
+/* log_posterior closure (fitting.py:121-128): -inf where a prior excludes the walker (likelihood skipped). */
+lcf_status lcf_log_posterior(lcf_engine* e, int64_t n, const double* P, double* out);
+/* Same with DEVICE pointers, enqueued on `stream` (a hipStream_t; NULL = the engine's own stream), no host sync. */
+lcf_status lcf_log_likelihood_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream);
+lcf_status lcf_log_posterior_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream);
+
+/* Model.__call__ / evaluate (models.py:86-87, pointwise branch :1161-1162): y_fit[n][n_points], original point order. */
+lcf_status lcf_model_evaluate(lcf_engine* e, int64_t n, const double* P, double* y_fit);
+/* temperature_radius (models.py:231-269, 583-597, 727-755): T_K, R_bb as [n][n_points]. */
+lcf_status lcf_temperature_radius(lcf_engine* e, int64_t n, const double* P, double* T_K, double* R_bb);
+/* blackbody_to_filters pointwise (models.py:1131-1165): out[m] = L_nu(filter filt_idx[m]; T[m], R[m]). */
+lcf_status lcf_blackbody_to_filters(lcf_engine* e, int64_t m, const int32_t* filt_idx, const double* T,
+                                    const double* R, double* out);
+
+/* Measurement hook for bench.py: average duration [ms] of the dominant kernel alone (the per-point likelihood
+ * kernel over n walkers), reps back-to-back launches bracketed by HIP events on the engine's stream. */
+lcf_status lcf_profile_loglike_kernel(lcf_engine* e, int64_t n, const double* P, int32_t reps, double* avg_ms);
+
+/* ---- device-resident ensemble sampler (replaces emcee.EnsembleSampler for this path, fitting.py:130-145) -------- */
+/* Goodman-Weare stretch move, red/blue halves, scale a.  RNG: Philox4x32-10 keyed by seed with counters
+ * (walker, step, half) -- independent of how walkers are sharded over devices. */
+lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, double a, lcf_sampler** out);
+void lcf_sampler_destroy(lcf_sampler* s);
+/* coords[n_walkers][n_dim] host; evaluates the initial log-posterior on the device. */
+lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords);
+lcf_status lcf_sampler_get_state(lcf_sampler* s, double* coords, double* log_prob);
+/* Red/blue colouring of each step.  RANDOM = emcee's randomize_split, generated on the device from (seed, step);
+ * HOST = caller-provided perm[n_steps][n_walkers] int32 (the first half of each row is colour 0). */
+enum { LCF_SPLIT_IDENTITY = 0, LCF_SPLIT_RANDOM = 1, LCF_SPLIT_HOST = 2 };
+/* Run n_steps ensemble steps numbered from first_step (the step number is an RNG counter word). */
+lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                           const int32_t* perm, int32_t store_chain);
+/* Chain of the last run: chain[n_steps][n_walkers][n_dim], log_prob[n_steps][n_walkers] (either may be NULL). */
+lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob);
+lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);
+/* Device time of the last lcf_sampler_run in milliseconds (HIP events on the sampler's stream). */
+double lcf_sampler_last_run_ms(const lcf_sampler* s);
+
+/* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
+ * log-probabilities (RCCL) between phase 2 and phase 3.  All enqueue on `stream` without host sync.
+ *   1. propose:  every rank draws the same proposals for the whole active half (replicated, cheap)
+ *   2. evaluate: this rank evaluates proposals [lo, hi) of the active half -> newlp[lo:hi)
+ *   3. accept:   every rank applies the same accept/reject to the whole half given the gathered newlp[0:n/2) */
+lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                             const int32_t* perm, int32_t store_chain);
+lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void* stream);
+lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream);
+lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* stream);
+/* Device pointer to newlp[n_walkers/2] (float64) for the collective. */
+void* lcf_sampler_newlp_ptr(lcf_sampler* s);
+lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGPROB if a NaN was seen */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCF_H */

@@ -1,0 +1,353 @@
+// Device-side model arithmetic for the gfx950 light-curve likelihood kernels.
+//
+// Everything here follows the *behaviour* of the reference's models.py / filters.py (cited per function) but is
+// organised for a 64-lane wavefront: one lane = one (walker, data point) pair, the walker's derived coefficients are
+// wave-uniform (scalar registers), the per-filter band tables sit in LDS as interleaved (a_k, W_k) pairs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcf {
+
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kNCoef = 8;        // derived per-walker coefficients
+constexpr int kMaxDim = 16;      // max parameters per walker
+constexpr int kLdsTabMax = 4000; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
+
+constexpr double kKB = 0.08617333262145178;   // eV / kK                 models.py:10
+constexpr double kC3 = 5.38477047522316e-19;  //                          models.py:11
+constexpr double kC3sq = kC3 * kC3;
+constexpr double kTwoPi = 6.283185307179586;
+// Above this temperature [kK] a_k/T < 1e-13 and the reference's exp(x) - 1 is pure cancellation noise (and 0 beyond
+// 1e17 kK); the engine returns a zero band integral there.  Physical fits stay below 1e3 kK.
+constexpr double kTmax = 1e15;
+
+enum Model : int {
+    kShockCooling = 1,
+    kShockCooling2 = 2,
+    kShockCooling4 = 4,
+    kCompanion = 5,
+    kCompanion2 = 6,
+    kCompanion3 = 7,
+    kBlackbody = 8
+};
+
+struct PriorDev {
+    int kind;
+    int pad;
+    double p_min, p_max, mean, stddev;
+};
+
+// Immutable per-problem device data (passed to kernels by value).
+struct DevProblem {
+    int model, n_points, n_chunks, n_filters;
+    int n_dim, n_par, use_sigma, sigma_abs;
+    int n_knots, has_priors, tab_in_lds, variant;
+    double consts[12];
+    double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
+    double sigma_unit_abs;  // median(dy)
+    // points, sorted by filter
+    const double* t;
+    const double* y;
+    const double* dy;
+    const int* pt_off;   // first table sample of the point's filter
+    const int* pt_cnt;   // number of table samples
+    const int* pt_filt;  // filter index
+    const int* pt_orig;  // index in the caller's order
+    const int* chunk_lo; // per chunk: first table sample needed
+    const int* chunk_n;  // per chunk: number of table samples needed
+    const double2* tab;  // (a_k, W_k)
+    const int* f_kpar;
+    const int* f_spar;
+    const int* f_dtpar;
+    const double* knots;
+    const double* spl;  // [n_filters][n_knots-1][4]
+    const PriorDev* priors;
+};
+
+// power() of the reference: base > 0 ? base**exp : 0, also for NaN bases.  models.py:42-48
+__device__ inline double pw(double base, double e) { return base > 0. ? pow(base, e) : 0.; }
+
+__device__ inline double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Band sum  S(T) = sum_k W_k / (exp(a_k / T) - 1)           filters.py:308-310 + models.py:1127-1128
+// ---------------------------------------------------------------------------------------------------------------
+
+// Variant 0: libm, shaped like the reference (one exp-minus-one and one divide per sample).
+template <class TabPtr>
+__device__ inline double band_sum_ref(TabPtr tab, int cnt, double invT) {
+    double acc = 0.;
+    for (int k = 0; k < cnt; ++k) {
+        const double2 aw = tab[k];
+        acc += aw.y / expm1(aw.x * invT);
+    }
+    return acc;
+}
+
+// exp(-x) for x >= 0 by a 64-entry table 2^(j/64) (registers of the polynomial stay wave-private; the table is in
+// LDS) and a degree-5 polynomial on |r| <= ln2/128.  Relative error < 2e-16 + |x| * 1.2e-16.
+// Underflows gradually and returns exactly 0 for x >= 746.5 (also for NaN).
+struct ExpTab {
+    const double* t;  // LDS: t[j] = 2^(-j/64), j = 0..63
+};
+
+__device__ inline double exp_neg(double x, const ExpTab et) {
+    // n = round(x * 64/ln2); x = n*ln2/64 + r
+    const double kInv = 92.33248261689366;        // 64 / ln 2
+    const double kHi = 0x1.62e42fef80000p-7;       // ln2/64 truncated to 35 bits: n*kHi is exact for n < 2^18
+    const double kLo = 0x1.1cf79abc9e3b4p-42;      // ln2/64 - kHi
+    x = fmin(x, 746.5);  // 2^-1076 * (p tj <= 1.01) rounds to exactly 0, like the reference's 1/inf
+    const double nf = rint(x * kInv);
+    double r = fma(nf, -kHi, x);
+    r = fma(nf, -kLo, r);  // r in [-ln2/128, ln2/128], we need exp(-r)
+    const int n = (int)nf;
+    const double tj = et.t[n & 63];
+    // exp(-r) = 1 - r + r^2/2 - r^3/6 + r^4/24 - r^5/120
+    double p = fma(r, -1. / 120., 1. / 24.);
+    p = fma(p, r, -1. / 6.);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, -1.);
+    p = fma(p, r, 1.);  // = exp(-r) up to r^6/720 < 3.4e-17
+    return ldexp(p * tj, -(n >> 6));
+}
+
+// Variant 1: u = exp(-x); W/(e^x - 1) = W u / (1 - u).  Four samples share one division:
+//   n1/d1 + n2/d2 = (n1 d2 + n2 d1) / (d1 d2)   with d in (0, 1], so nothing overflows; products of four d's
+//   stay far above the subnormal range unless all four x < 1e-77, which the guard below excludes.
+template <class TabPtr>
+__device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const ExpTab et) {
+    double acc = 0.;
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+        const double2 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
+        const double u0 = exp_neg(s0.x * invT, et), u1 = exp_neg(s1.x * invT, et);
+        const double u2 = exp_neg(s2.x * invT, et), u3 = exp_neg(s3.x * invT, et);
+        const double d0 = 1. - u0, d1 = 1. - u1, d2 = 1. - u2, d3 = 1. - u3;
+        const double n01 = fma(s0.y * u0, d1, s1.y * u1 * d0), d01 = d0 * d1;
+        const double n23 = fma(s2.y * u2, d3, s3.y * u3 * d2), d23 = d2 * d3;
+        acc += fma(n01, d23, n23 * d01) / (d01 * d23);
+    }
+    for (; k < cnt; ++k) {
+        const double2 s = tab[k];
+        const double u = exp_neg(s.x * invT, et);
+        acc += s.y * u / (1. - u);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-walker derived coefficients (wave-uniform).  One thread per walker computes them once; the likelihood kernel
+// reads them through scalar loads.
+//   c[0] = explosion time t_0
+//   power-law thermal models (ShockCooling, ShockCooling2):
+//     T_K(t) = c[1] t^eT,  L(t) = c[2] t^eL exp(-(g t)^alpha) with c[3] = alpha ln g (NaN: no cut-off term),
+//     c[4] != 0: a negative phase yields NaN (L < 0 before the explosion)
+//   ShockCooling4:  c[1] = T_col_br/k_B, c[2] = L_br, c[3] = t_br, c[4] = t_tr
+//   Companion:      c[1] = T coefficient, c[2] = R^2 coefficient, c[3] = t_peak, c[4] = stretch, c[5] = shock factor
+//   Blackbody:      c[1] = T, c[2] = R^2
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p, double* __restrict__ c) {
+    const double* k = pb.consts;
+    for (int i = 0; i < kNCoef; ++i) c[i] = 0.;
+    switch (pb.model) {
+        case kShockCooling: {  // models.py:260-267
+            const double A = k[0], a = k[1], alpha = k[2], eps1 = k[3], eps2 = k[4], L0 = k[5], T0 = k[6], ratio = k[7];
+            const double v = p[0], M = p[1], f = p[2], R = p[3];
+            const double Lc = L0 * pw(v / f, -eps2) * v * v * R;  // L_RW = Lc * |t|^(-2 eps2)
+            const double t_tr = 19.5 * sqrt(M / v);
+            const double g = a / t_tr;
+            c[0] = p[4];
+            c[1] = T0 * pw(v * v / f, eps1) * pow(R, 0.25) * ratio / kKB;
+            c[2] = Lc * A;
+            c[3] = g > 0. ? alpha * log(g) : qnan();
+            c[4] = (Lc >= 0.) ? 0. : 1.;
+            break;
+        }
+        case kShockCooling2: {  // models.py:403-406
+            const double a = k[1], alpha = k[2];
+            const double g = a / p[2];
+            c[0] = p[3];
+            c[1] = p[0];
+            c[2] = p[1] * 1e42;
+            c[3] = g > 0. ? alpha * log(g) : qnan();
+            break;
+        }
+        case kShockCooling4: {  // models.py:584-587 (quirks kept: no kappa in t_br, right-associative ** chain)
+            const double v = p[0], M = p[1], f = p[2], R = p[3];
+            c[0] = p[4];
+            c[1] = k[4] * pow(R, -0.32) * pow(v, pow(0.58, pow(f, 0.03))) / kKB;
+            c[2] = k[3] * pow(R, 0.78) * pow(v, 2.11) * pow(f, 0.11);
+            c[3] = k[5] * pow(R, 1.26) * pow(v, -1.13) * pow(f, -0.13);
+            c[4] = k[6] * sqrt(M / v);
+            break;
+        }
+        case kCompanion:
+        case kCompanion2:
+        case kCompanion3: {  // models.py:752-755, 1040-1044
+            const double a13 = p[1];
+            const double Mv = pb.model == kCompanion3 ? 1. : p[2];
+            c[0] = p[0];
+            c[1] = 25. * pw(pow(a13, 36.) * Mv, 1. / 144.);
+            const double rc = 2.7 * pw(Mv, 1. / 9.);
+            c[2] = rc * rc;
+            c[3] = p[3];
+            c[4] = p[4];
+            if (pb.model == kCompanion3) {
+                const double th = p[2] * 0.017453292519943295;
+                c[5] = (0.5 * cos(th) + 0.5) * (0.14 * th * th - 0.4 * th + 1.);
+            } else {
+                c[5] = 1.;
+            }
+            break;
+        }
+        case kBlackbody:
+            c[1] = p[0];
+            c[2] = p[1] * p[1];
+            break;
+        default:
+            break;
+    }
+}
+
+// log-prior of one walker; -inf outside the strict bounds.  models.py:1055-1098, fitting.py:122-126
+__device__ inline double walker_log_prior(const DevProblem& pb, const double* __restrict__ p) {
+    if (!pb.has_priors) return 0.;
+    double lp = 0.;
+    for (int i = 0; i < pb.n_dim; ++i) {
+        const PriorDev pr = pb.priors[i];
+        const double x = p[i];
+        if (!(pr.p_min < x && x < pr.p_max)) return -INFINITY;
+        if (pr.kind == 1) {
+            lp -= log(x);
+        } else if (pr.kind == 2) {
+            const double u = (x - pr.mean) / pr.stddev;
+            lp -= 0.5 * u * u;
+        }
+    }
+    return lp;
+}
+
+// Piecewise-cubic SiFTO template, 0 outside the knot range (and for NaN arguments).  models.py:717, 816-826
+__device__ inline double spline_eval(const double* __restrict__ knots, int nk, const double* __restrict__ coef,
+                                     double x) {
+    if (!(x >= knots[0] && x <= knots[nk - 1])) return 0.;
+    int lo = 0, hi = nk - 1;  // invariant: knots[lo] <= x <= knots[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (x >= knots[mid]) lo = mid; else hi = mid;
+    }
+    const double dx = x - knots[lo];
+    const double* q = coef + 4 * lo;
+    return fma(fma(fma(q[0], dx, q[1]), dx, q[2]), dx, q[3]);
+}
+
+// Temperature [kK] and the factor `pref` such that  L_nu = pref * S(T)  (pref = R_bb^2), for one data point.
+// Sets T = 0 (and pref = 0 or NaN) where the reference's power() zeroing makes the band integral vanish.
+__device__ inline void thermal_state(const DevProblem& pb, const double* __restrict__ c, double t_in, double& T,
+                                     double& pref) {
+    const double* k = pb.consts;
+    const double t = t_in - c[0];
+    T = 0.;
+    pref = 0.;
+    switch (pb.model) {
+        case kShockCooling:
+        case kShockCooling2: {
+            const double eps1 = k[3], eps2 = k[4], alpha = k[2];
+            if (t > 0.) {
+                const double lt = log(t);
+                const double Tk = c[1] * exp((2. * eps1 - 0.5) * lt);
+                const double E = (c[3] == c[3]) ? exp(fma(alpha, lt, c[3])) : 0.;
+                const double L = c[2] * exp(-2. * eps2 * lt - E);
+                if (!(L >= 0.)) {
+                    pref = qnan();
+                } else if (Tk > 0. && Tk < kTmax) {
+                    const double i2 = 1. / (Tk * Tk);
+                    T = Tk;
+                    pref = kC3sq * L * i2 * i2;  // R_bb^2 = c3^2 L T^-4      models.py:268
+                }  // else: T <= 0 or NaN -> power(T, -2) = 0 -> R_bb = 0
+            } else if (t < 0. && c[4] != 0.) {
+                pref = qnan();  // sqrt(L) with L < 0 before the explosion
+            }
+            break;
+        }
+        case kShockCooling4: {  // models.py:588-597
+            const double tt = t / c[3];
+            double P1 = 0., P2 = 0., P3 = 0., P4 = 0.;
+            if (tt > 0.) {
+                const double ltt = log(tt);
+                P1 = exp(-4. / 3. * ltt);
+                P2 = exp(-0.17 * ltt);
+                P3 = exp(-1. / 3. * ltt);
+                P4 = exp(-0.45 * ltt);
+            }
+            const double u = k[1] * t / c[4];
+            const double E = u > 0. ? pow(u, k[2]) : 0.;
+            const double L = c[2] * (P1 + k[0] * exp(-E) * P2);
+            const double Tk = c[1] * fmin(0.97 * P3, P4);
+            if (!(L >= 0.)) {
+                pref = qnan();
+            } else if (Tk > 0. && Tk < kTmax) {
+                const double i2 = 1. / (Tk * Tk);
+                T = Tk;
+                pref = kC3sq * L * i2 * i2;
+            }
+            break;
+        }
+        case kCompanion:
+        case kCompanion2:
+        case kCompanion3: {  // models.py:752-755
+            if (t > 0.) {
+                const double lt = log(t);
+                // power(t, -74) overflows to inf below t ~ 6.8e-5 d (T = inf -> band integral 0) and underflows to 0
+                // above t ~ 2.3e4 d (T = 0), exactly as in the reference's evaluation order.
+                if (lt > -9.5916 && lt < 10.06) {
+                    const double Tk = c[1] * exp(-74. / 144. * lt);
+                    if (Tk > 0. && Tk < kTmax) {
+                        T = Tk;
+                        pref = c[2] * exp(14. / 9. * lt);  // R^2 = (2.7 (Mv t^7)^(1/9))^2
+                    }
+                }
+            }
+            break;
+        }
+        case kBlackbody:
+            if (c[1] > 0. && c[1] < kTmax) {
+                T = c[1];
+                pref = c[2];
+            } else if (c[2] != c[2]) {
+                pref = qnan();
+            }
+            break;
+        default:
+            break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a draw depends only on (seed, walker, step, half).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                  uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform in (0,1) from two words: 52 random bits + 1/2, exactly representable
+__device__ inline double u01(uint32_t hi, uint32_t lo) {
+    const uint64_t v = ((uint64_t)hi << 20) ^ ((uint64_t)lo >> 12);
+    return ((double)v + 0.5) * (1. / 4503599627370496.);
+}
+
+}  // namespace lcf

@@ -1,0 +1,979 @@
+// MI355X (gfx950) batched light-curve log-likelihood engine: kernels + C ABI (include/lcf.h).
+//
+// Data layout in HBM (all float64 unless noted):
+//   photometry  t[N], y[N], dy[N], int32 pt_off[N], pt_cnt[N], pt_filt[N], pt_orig[N]   -- sorted by filter
+//   band tables tab[sum K] as interleaved (a_k, W_k) pairs (16 B, one ds_read_b128 per sample)
+//   walkers     P[n][n_dim] row-major; derived coefficients coef[n][8]; partial chi^2 sums part[n][n_chunks]
+// Work decomposition: workgroup = (walker w, chunk c of 256 filter-sorted points); lane = one data point.  The
+// chunk's band-table slice is staged in LDS once per workgroup; lanes of a wave read the same LDS address
+// (broadcast) because neighbouring points share a filter.  Reductions are wave shuffles + a fixed-order LDS sum:
+// no float atomics anywhere, results are bitwise reproducible run to run and independent of the GPU count.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "lcf.h"
+#include "lcf_device.h"
+
+using namespace lcf;
+
+// =================================================================================================================
+// kernels
+// =================================================================================================================
+namespace {
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One thread per walker: derived coefficients, log-prior, skip flag.
+__global__ void k_prepare(const DevProblem pb, int n, const double* __restrict__ P, double* __restrict__ coef,
+                          double* __restrict__ lprior, int with_prior) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const double* p = P + (size_t)w * pb.n_dim;
+    double c[kNCoef];
+    walker_coefficients(pb, p, c);
+    for (int i = 0; i < kNCoef; ++i) coef[(size_t)w * kNCoef + i] = c[i];
+    lprior[w] = with_prior ? walker_log_prior(pb, p) : 0.;
+}
+
+struct PointOut {
+    double yfit;
+    double T;
+    double pref;
+};
+
+// Everything one lane does for its data point: thermal state -> band sum(s) -> template term.
+template <int VARIANT, class TabPtr>
+__device__ inline PointOut point_model(const DevProblem& pb, const double* __restrict__ c,
+                                       const double* __restrict__ p, double t_in, int filt, TabPtr tab, int cnt,
+                                       const ExpTab et) {
+    PointOut o;
+    thermal_state(pb, c, t_in, o.T, o.pref);
+    double S = 0.;
+    if (o.T > 0.) {
+        const double invT = 1. / o.T;
+        S = VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
+        if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
+            const double invT2 = invT * (1. / 0.74);
+            const double S2 = VARIANT == 0 ? band_sum_ref(tab, cnt, invT2) : band_sum_fast(tab, cnt, invT2, et);
+            S = fmin(S, S2 * (1. / (0.74 * 0.74 * 0.74 * 0.74)));
+        }
+    }
+    // pref may be NaN (propagates) or 0 with T == 0.
+    o.yfit = (o.pref != o.pref) ? o.pref : o.pref * S;
+    if (pb.model >= kCompanion && pb.model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
+        const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
+        const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
+        const double sfac = sp >= 0 ? p[sp] : 1.;
+        const double dt = dp >= 0 ? p[dp] : 0.;
+        const double x = (t_in - c[3] - dt) / c[4];
+        const double tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x);
+        o.yfit = o.yfit * kfac + tmpl * sfac;
+    }
+    return o;
+}
+
+// MODE 0: chi^2 partial sums -> part[w][chunk];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
+template <int VARIANT, int MODE, bool LDS_TAB>
+__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, const double* __restrict__ P,
+                                                   const double* __restrict__ coef,
+                                                   const double* __restrict__ lprior, double* __restrict__ out0,
+                                                   double* __restrict__ out1) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* exptab = reinterpret_cast<double*>(smem);                     // 64 doubles
+    double* red = exptab + 64;                                            // 4 doubles
+    double2* ltab = reinterpret_cast<double2*>(smem + (64 + 8) * sizeof(double));
+
+    const int chunk = blockIdx.x % pb.n_chunks;
+    const int w = w_lo + blockIdx.x / pb.n_chunks;
+    const int tid = threadIdx.x;
+
+    if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
+
+    if (VARIANT == 1 && tid < 64) exptab[tid] = exp2(-(double)tid * (1. / 64.));
+    const int tlo = pb.chunk_lo[chunk];
+    if (LDS_TAB) {
+        const int tn = pb.chunk_n[chunk];
+        for (int k = tid; k < tn; k += kBlock) ltab[k] = pb.tab[tlo + k];
+    }
+    __syncthreads();
+
+    const double* c = coef + (size_t)w * kNCoef;   // wave-uniform -> scalar loads
+    const double* p = P + (size_t)w * pb.n_dim;
+    const ExpTab et{exptab};
+
+    const int i = chunk * kBlock + tid;
+    double term = 0.;
+    if (i < pb.n_points) {
+        const double t_in = pb.t[i];
+        const int filt = pb.pt_filt[i];
+        const int off = pb.pt_off[i], cnt = pb.pt_cnt[i];
+        PointOut o;
+        if (LDS_TAB) {
+            o = point_model<VARIANT>(pb, c, p, t_in, filt, (const double2*)(ltab + (off - tlo)), cnt, et);
+        } else {
+            o = point_model<VARIANT>(pb, c, p, t_in, filt, pb.tab + off, cnt, et);
+        }
+        if (MODE == 0) {  // models.py:121-135
+            const double dy = pb.dy[i];
+            const double r = pb.y[i] - o.yfit;
+            if (pb.use_sigma) {
+                const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
+                const double var = fma(dy, dy, su * su);
+                term = log(kTwoPi * var) + r * r / var;
+            } else {
+                const double q = r / dy;
+                term = q * q;
+            }
+        } else if (MODE == 1) {
+            out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = o.yfit;
+        } else {
+            // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
+            const size_t j = (size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i];
+            out0[j] = o.T;
+            out1[j] = sqrt(o.pref);
+        }
+    }
+    if (MODE == 0) {
+        const double ws = wave_sum(term);
+        if ((tid & 63) == 0) red[tid >> 6] = ws;
+        __syncthreads();
+        if (tid == 0) out0[(size_t)w * pb.n_chunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// lnL (and log-posterior) per walker from the partial sums, fixed summation order.
+__global__ void k_finalize(const DevProblem pb, int n, const double* __restrict__ part,
+                           const double* __restrict__ lprior, double* __restrict__ out) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const double lp = lprior[w];
+    if (lp == -INFINITY) {
+        out[w] = -INFINITY;
+        return;
+    }
+    double s = pb.use_sigma ? 0. : pb.log_norm_const;
+    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)w * pb.n_chunks + k];
+    out[w] = lp - 0.5 * s;
+}
+
+// blackbody_to_filters, pointwise (models.py:1161-1162): arbitrary (filter, T, R) triples.
+template <int VARIANT>
+__global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, int m, const int* __restrict__ filt,
+                                                         const int* __restrict__ tab_off,
+                                                         const double* __restrict__ T, const double* __restrict__ R,
+                                                         double* __restrict__ out) {
+    __shared__ double exptab[64];
+    if (threadIdx.x < 64) exptab[threadIdx.x] = exp2(-(double)threadIdx.x * (1. / 64.));
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int f = filt[i];
+    const int off = tab_off[f], cnt = tab_off[f + 1] - off;
+    const double Tk = T[i], r = R[i];
+    double S = 0.;
+    if (Tk > 0. && Tk < kTmax) {
+        const ExpTab et{exptab};
+        S = VARIANT == 0 ? band_sum_ref(pb.tab + off, cnt, 1. / Tk) : band_sum_fast(pb.tab + off, cnt, 1. / Tk, et);
+    }
+    out[i] = r * r * S;
+}
+
+// ---- ensemble sampler ---------------------------------------------------------------------------------------------
+struct DevSampler {
+    int n_walkers, n_half, n_dim, store_chain;
+    uint32_t key0, key1;
+    double a;
+    double* X;        // [n_walkers][n_dim]
+    double* LP;       // [n_walkers]
+    double* Q;        // [n_half][n_dim]
+    double* zl;       // [n_half] (n_dim - 1) ln z
+    double* lnu;      // [n_half]
+    int* act;         // [n_half] walker ids of the active half
+    double* newlp;    // [n_half]
+    double* chain;    // [n_steps][n_walkers][n_dim]
+    double* chain_lp; // [n_steps][n_walkers]
+    long long* nacc;  // [n_walkers]
+    int* err;
+};
+
+// Random red/blue colouring of each step (emcee's randomize_split): one workgroup per step ranks the walkers by a
+// 50-bit Philox key (ties impossible: the walker id fills the low 14 bits) with a bitonic sort in LDS.
+// perm[step][0 .. n/2) is colour 0.  Deterministic in (seed, step): every rank of a multi-GPU run derives the same
+// split without communicating.
+__global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, uint32_t key0, uint32_t key1,
+                                                    long long first_step, int* __restrict__ perm) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+    const long long step = first_step + blockIdx.x;
+    for (int w = threadIdx.x; w < n_pad; w += blockDim.x) {
+        unsigned long long k = ~0ull;
+        if (w < n_walkers) {
+            uint32_t r[4];
+            philox4x32((uint32_t)w, (uint32_t)step, 2u, 7u, key0, key1, r);
+            const unsigned long long h = ((unsigned long long)r[0] << 32) | r[1];
+            k = (h & ~0x3fffull) | (unsigned long long)w;
+        }
+        keys[w] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n_pad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < (n_pad >> 1); i += blockDim.x) {
+                const int lo = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int w = threadIdx.x; w < n_walkers; w += blockDim.x)
+        perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
+}
+
+// Stretch-move proposal for the active half + the proposal's derived coefficients and log-prior (fused prepare).
+__global__ void k_propose(const DevProblem pb, const DevSampler sm, const int* __restrict__ perm, long long step,
+                          long long chain_row, int half, double* __restrict__ coef, double* __restrict__ lprior) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sm.n_half) return;
+    const int n_other = sm.n_walkers - sm.n_half;
+    const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
+    const int wid = perm ? perm[my_slot] : my_slot;
+    uint32_t r[4], s[4];
+    philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 0u, sm.key0, sm.key1, r);
+    philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 1u, sm.key0, sm.key1, s);
+    const double uz = u01(r[0], r[1]);
+    const double zr = (sm.a - 1.) * uz + 1.;
+    const double z = zr * zr / sm.a;
+    int j = (int)(u01(r[2], r[3]) * (double)n_other);
+    j = min(j, n_other - 1);
+    const int other_slot = half == 0 ? sm.n_half + j : j;
+    const int pid = perm ? perm[other_slot] : other_slot;
+    double q[kMaxDim];
+    for (int d = 0; d < sm.n_dim; ++d) {
+        const double cj = sm.X[(size_t)pid * sm.n_dim + d];
+        const double xi = sm.X[(size_t)wid * sm.n_dim + d];
+        q[d] = cj - (cj - xi) * z;
+        sm.Q[(size_t)i * sm.n_dim + d] = q[d];
+    }
+    sm.act[i] = wid;
+    sm.zl[i] = (double)(sm.n_dim - 1) * log(z);
+    sm.lnu[i] = log(u01(s[0], s[1]));
+    double c[kNCoef];
+    walker_coefficients(pb, q, c);
+    for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
+    lprior[i] = walker_log_prior(pb, q);
+    (void)chain_row;
+}
+
+// Accept / reject for the active half, chain bookkeeping.  Reads the gathered new log-posteriors.
+__global__ void k_accept(const DevSampler sm, long long chain_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sm.n_half) return;
+    const int wid = sm.act[i];
+    const double nlp = sm.newlp[i];
+    const double old = sm.LP[wid];
+    if (nlp != nlp) atomicExch(sm.err, 1);
+    const bool ok = (sm.zl[i] + nlp - old) > sm.lnu[i];
+    double lp = old;
+    if (ok) {
+        for (int d = 0; d < sm.n_dim; ++d) sm.X[(size_t)wid * sm.n_dim + d] = sm.Q[(size_t)i * sm.n_dim + d];
+        sm.LP[wid] = nlp;
+        sm.nacc[wid] += 1;
+        lp = nlp;
+    }
+    if (sm.store_chain) {
+        double* row = sm.chain + ((size_t)chain_row * sm.n_walkers + wid) * sm.n_dim;
+        for (int d = 0; d < sm.n_dim; ++d) row[d] = ok ? sm.Q[(size_t)i * sm.n_dim + d] : sm.X[(size_t)wid * sm.n_dim + d];
+        sm.chain_lp[(size_t)chain_row * sm.n_walkers + wid] = lp;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================================
+// host side
+// =================================================================================================================
+namespace {
+
+thread_local std::string g_err;
+
+lcf_status fail(lcf_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define LCF_HIP(call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? LCF_ERR_OUT_OF_MEMORY : LCF_ERR_HIP,                   \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+template <class T>
+lcf_status upload(const std::vector<T>& h, T** d, std::vector<void*>& owned) {
+    *d = nullptr;
+    if (h.empty()) return LCF_OK;
+    LCF_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
+    owned.push_back(*d);
+    LCF_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LCF_OK;
+}
+
+}  // namespace
+
+struct lcf_engine {
+    int device = 0;
+    DevProblem dp{};
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    int64_t samples_per_eval = 0;
+    size_t lds_bytes = 0;
+    int* d_tab_off = nullptr;
+    // workspace for n walkers
+    int64_t cap = 0;
+    double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
+    // scratch for evaluate-type calls
+    size_t big_bytes = 0;
+    double* wbig = nullptr;
+
+    ~lcf_engine() {
+        hipSetDevice(device);
+        for (void* p : owned) hipFree(p);
+        free_ws();
+        if (wbig) hipFree(wbig);
+        if (stream) hipStreamDestroy(stream);
+    }
+    void free_ws() {
+        for (double** p : {&wP, &wcoef, &wlprior, &wpart, &wout}) {
+            if (*p) hipFree(*p);
+            *p = nullptr;
+        }
+        cap = 0;
+    }
+    lcf_status reserve(int64_t n) {
+        if (n <= cap) return LCF_OK;
+        LCF_HIP(hipStreamSynchronize(stream));
+        free_ws();
+        const int64_t c = std::max<int64_t>(n, 64);
+        LCF_HIP(hipMalloc((void**)&wP, c * dp.n_dim * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wcoef, c * kNCoef * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wlprior, c * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wpart, c * dp.n_chunks * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wout, c * sizeof(double)));
+        cap = c;
+        return LCF_OK;
+    }
+    lcf_status reserve_big(size_t bytes) {
+        if (bytes <= big_bytes) return LCF_OK;
+        LCF_HIP(hipStreamSynchronize(stream));
+        if (wbig) hipFree(wbig);
+        wbig = nullptr;
+        big_bytes = 0;
+        LCF_HIP(hipMalloc((void**)&wbig, bytes));
+        big_bytes = bytes;
+        return LCF_OK;
+    }
+};
+
+namespace {
+
+template <int MODE>
+void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const double* coef, const double* lprior,
+                   double* out0, double* out1, hipStream_t st) {
+    const DevProblem& pb = e->dp;
+    const dim3 grid((unsigned)((size_t)n * pb.n_chunks)), block(kBlock);
+    const size_t lds = e->lds_bytes;
+    if (pb.variant == 0) {
+        if (pb.tab_in_lds)
+            hipLaunchKernelGGL((k_points<0, MODE, true>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+        else
+            hipLaunchKernelGGL((k_points<0, MODE, false>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+    } else {
+        if (pb.tab_in_lds)
+            hipLaunchKernelGGL((k_points<1, MODE, true>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+        else
+            hipLaunchKernelGGL((k_points<1, MODE, false>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+    }
+}
+
+// log-likelihood / log-posterior of n walkers, device pointers, enqueue only.
+lcf_status logprob_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, hipStream_t st, int with_prior) {
+    if (n == 0) return LCF_OK;
+    const int bs = 128;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, e->dp, (int)n, dP, e->wcoef,
+                       e->wlprior, with_prior);
+    launch_points<0>(e, 0, (int)n, dP, e->wcoef, e->wlprior, e->wpart, nullptr, st);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, e->dp, (int)n, e->wpart,
+                       e->wlprior, dout);
+    LCF_HIP(hipGetLastError());
+    return LCF_OK;
+}
+
+lcf_status logprob_host(lcf_engine* e, int64_t n, const double* P, double* out, int with_prior) {
+    if (!e || n < 0 || (n > 0 && (!P || !out))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return LCF_OK;
+    if (n > (1 << 22)) return fail(LCF_ERR_INVALID_ARGUMENT, "at most 2^22 walkers per call");
+    LCF_HIP(hipSetDevice(e->device));
+    if (lcf_status st = e->reserve(n)) return st;
+    LCF_HIP(hipMemcpyAsync(e->wP, P, n * e->dp.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (lcf_status st = logprob_dev(e, n, e->wP, e->wout, e->stream, with_prior)) return st;
+    LCF_HIP(hipMemcpyAsync(out, e->wout, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    LCF_HIP(hipStreamSynchronize(e->stream));
+    return LCF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t lcf_abi_version(void) { return LCF_ABI_VERSION; }
+
+const char* lcf_last_error(void) { return g_err.c_str(); }
+
+int32_t lcf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine** out) {
+    if (!pr || !out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (pr->abi_version != LCF_ABI_VERSION) return fail(LCF_ERR_INVALID_ARGUMENT, "abi_version mismatch");
+    switch (pr->model) {
+        case LCF_MODEL_SHOCK_COOLING: case LCF_MODEL_SHOCK_COOLING2: case LCF_MODEL_SHOCK_COOLING4:
+        case LCF_MODEL_COMPANION_SHOCKING: case LCF_MODEL_COMPANION_SHOCKING2: case LCF_MODEL_COMPANION_SHOCKING3:
+        case LCF_MODEL_BLACKBODY:
+            break;
+        default:
+            return fail(LCF_ERR_UNSUPPORTED, "unknown or unsupported model id");
+    }
+    static const int kNPar[9] = {0, 5, 4, 0, 5, 8, 7, 7, 2};
+    if (pr->n_par != kNPar[pr->model]) return fail(LCF_ERR_INVALID_ARGUMENT, "n_par does not match the model");
+    const int n_dim = pr->n_par + (pr->use_sigma ? 1 : 0);
+    if (n_dim > kMaxDim) return fail(LCF_ERR_INVALID_ARGUMENT, "too many parameters");
+    if (pr->n_points < 0 || pr->n_points > (1 << 26) || pr->n_filters <= 0)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad n_points / n_filters");
+    if (pr->n_points > 0 && (!pr->t || !pr->y || !pr->dy || !pr->filt_idx))
+        return fail(LCF_ERR_INVALID_ARGUMENT, "null photometry");
+    if (!pr->tab_off || !pr->tab_a || !pr->tab_w) return fail(LCF_ERR_INVALID_ARGUMENT, "null band tables");
+    if (pr->sigma_type != LCF_SIGMA_RELATIVE && pr->sigma_type != LCF_SIGMA_ABSOLUTE)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "sigma_type must be relative or absolute");
+    const int N = (int)pr->n_points, NF = pr->n_filters;
+    if (pr->tab_off[0] != 0) return fail(LCF_ERR_INVALID_ARGUMENT, "tab_off[0] must be 0");
+    for (int f = 0; f < NF; ++f)
+        if (pr->tab_off[f + 1] < pr->tab_off[f]) return fail(LCF_ERR_INVALID_ARGUMENT, "tab_off must be non-decreasing");
+    for (int i = 0; i < N; ++i)
+        if (pr->filt_idx[i] < 0 || pr->filt_idx[i] >= NF) return fail(LCF_ERR_INVALID_ARGUMENT, "filt_idx out of range");
+    const bool companion = pr->model >= LCF_MODEL_COMPANION_SHOCKING && pr->model <= LCF_MODEL_COMPANION_SHOCKING3;
+    if (companion) {
+        if (!pr->filt_kasen_par || !pr->filt_sifto_par || !pr->filt_dt_par || !pr->spline_knots || !pr->spline_coef ||
+            pr->n_knots < 2)
+            return fail(LCF_ERR_INVALID_ARGUMENT, "companion-shocking model needs spline and factor tables");
+        for (int f = 0; f < NF; ++f)
+            for (const int32_t* a : {pr->filt_kasen_par, pr->filt_sifto_par, pr->filt_dt_par})
+                if (a[f] < -1 || a[f] >= n_dim) return fail(LCF_ERR_INVALID_ARGUMENT, "factor parameter index out of range");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(LCF_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(LCF_ERR_INVALID_ARGUMENT, "device index out of range");
+    LCF_HIP(hipSetDevice(device));
+
+    auto* e = new lcf_engine();
+    e->device = device;
+    lcf_status st = LCF_OK;
+    auto bail = [&](lcf_status s) {
+        delete e;
+        return s;
+    };
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(LCF_ERR_HIP, "hipStreamCreate failed"));
+
+    // ---- sort points by filter (stable), build per-point table slices and per-chunk LDS windows ----
+    std::vector<int> order(N);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pr->filt_idx[a] < pr->filt_idx[b]; });
+    std::vector<double> ht(N), hy(N), hdy(N);
+    std::vector<int> hoff(N), hcnt(N), hfilt(N), horig(N);
+    double lognorm = 0.;
+    int64_t samples = 0;
+    for (int i = 0; i < N; ++i) {
+        const int o = order[i], f = pr->filt_idx[o];
+        ht[i] = pr->t[o];
+        hy[i] = pr->y[o];
+        hdy[i] = pr->dy[o];
+        hfilt[i] = f;
+        horig[i] = o;
+        hoff[i] = pr->tab_off[f];
+        hcnt[i] = pr->tab_off[f + 1] - pr->tab_off[f];
+        samples += hcnt[i];
+    }
+    for (int i = 0; i < N; ++i) lognorm += std::log(2. * M_PI * pr->dy[i] * pr->dy[i]);  // caller order, like np.sum
+    std::vector<double> sorted_dy(pr->dy, pr->dy + N);
+    double med = 0.;
+    if (N > 0) {  // np.median
+        std::sort(sorted_dy.begin(), sorted_dy.end());
+        med = (N & 1) ? sorted_dy[N / 2] : 0.5 * (sorted_dy[N / 2 - 1] + sorted_dy[N / 2]);
+    }
+    const int n_chunks = std::max(1, (N + kBlock - 1) / kBlock);
+    std::vector<int> clo(n_chunks, 0), cn(n_chunks, 0);
+    int max_cn = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int a = c * kBlock, b = std::min(N, a + kBlock);
+        if (a >= b) continue;
+        int lo = hoff[a], hi = hoff[a] + hcnt[a];
+        for (int i = a; i < b; ++i) {
+            lo = std::min(lo, hoff[i]);
+            hi = std::max(hi, hoff[i] + hcnt[i]);
+        }
+        clo[c] = lo;
+        cn[c] = hi - lo;
+        max_cn = std::max(max_cn, cn[c]);
+    }
+    const int ntab = pr->tab_off[NF];
+    std::vector<double2> htab(ntab);
+    for (int k = 0; k < ntab; ++k) htab[k] = make_double2(pr->tab_a[k], pr->tab_w[k]);
+    std::vector<int> htaboff(pr->tab_off, pr->tab_off + NF + 1);
+
+    DevProblem& dp = e->dp;
+    dp.model = pr->model;
+    dp.n_points = N;
+    dp.n_chunks = n_chunks;
+    dp.n_filters = NF;
+    dp.n_dim = n_dim;
+    dp.n_par = pr->n_par;
+    dp.use_sigma = pr->use_sigma ? 1 : 0;
+    dp.sigma_abs = pr->sigma_type == LCF_SIGMA_ABSOLUTE;
+    dp.n_knots = companion ? pr->n_knots : 0;
+    dp.has_priors = pr->priors ? 1 : 0;
+    dp.tab_in_lds = max_cn <= kLdsTabMax;
+    dp.variant = 1;
+    std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
+    dp.log_norm_const = lognorm;
+    dp.sigma_unit_abs = med;
+    e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
+    e->lds_bytes = (64 + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)std::max(max_cn, 1) * sizeof(double2) : 0);
+
+    double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
+    int *doff, *dcnt, *dfilt, *dorig, *dclo, *dcn, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
+    double2* dtab;
+    PriorDev* dpri = nullptr;
+#define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
+    UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hoff, doff); UP(hcnt, dcnt); UP(hfilt, dfilt); UP(horig, dorig);
+    UP(clo, dclo); UP(cn, dcn); UP(htab, dtab); UP(htaboff, e->d_tab_off);
+    if (companion) {
+        std::vector<int> hk(pr->filt_kasen_par, pr->filt_kasen_par + NF), hs(pr->filt_sifto_par, pr->filt_sifto_par + NF),
+            hd(pr->filt_dt_par, pr->filt_dt_par + NF);
+        std::vector<double> hkn(pr->spline_knots, pr->spline_knots + pr->n_knots),
+            hsp(pr->spline_coef, pr->spline_coef + (size_t)NF * (pr->n_knots - 1) * 4);
+        for (int k = 1; k < pr->n_knots; ++k)
+            if (!(hkn[k] > hkn[k - 1])) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "spline knots must ascend"));
+        UP(hk, dk); UP(hs, ds); UP(hd, ddt); UP(hkn, dkn); UP(hsp, dspl);
+    }
+    if (pr->priors) {
+        std::vector<PriorDev> hp(n_dim);
+        for (int i = 0; i < n_dim; ++i) {
+            if (pr->priors[i].kind < 0 || pr->priors[i].kind > 2) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "bad prior kind"));
+            hp[i] = PriorDev{pr->priors[i].kind, 0, pr->priors[i].p_min, pr->priors[i].p_max, pr->priors[i].mean,
+                             pr->priors[i].stddev};
+        }
+        UP(hp, dpri);
+    }
+#undef UP
+    dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_off = doff; dp.pt_cnt = dcnt; dp.pt_filt = dfilt; dp.pt_orig = dorig;
+    dp.chunk_lo = dclo; dp.chunk_n = dcn; dp.tab = dtab; dp.f_kpar = dk; dp.f_spar = ds; dp.f_dtpar = ddt;
+    dp.knots = dkn; dp.spl = dspl; dp.priors = dpri;
+    *out = e;
+    return LCF_OK;
+}
+
+void lcf_engine_destroy(lcf_engine* e) { delete e; }
+int32_t lcf_engine_ndim(const lcf_engine* e) { return e ? e->dp.n_dim : 0; }
+int64_t lcf_engine_npoints(const lcf_engine* e) { return e ? e->dp.n_points : 0; }
+int64_t lcf_engine_samples_per_eval(const lcf_engine* e) { return e ? e->samples_per_eval : 0; }
+
+lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant) {
+    if (!e || variant < 0 || variant > 1) return fail(LCF_ERR_INVALID_ARGUMENT, "variant must be 0 or 1");
+    e->dp.variant = variant;
+    return LCF_OK;
+}
+
+lcf_status lcf_log_likelihood(lcf_engine* e, int64_t n, const double* P, double* out) {
+    return logprob_host(e, n, P, out, 0);
+}
+lcf_status lcf_log_posterior(lcf_engine* e, int64_t n, const double* P, double* out) {
+    return logprob_host(e, n, P, out, 1);
+}
+lcf_status lcf_log_likelihood_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream) {
+    if (!e || n < 0 || (n > 0 && (!dP || !dout))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(e->device));
+    if (lcf_status st = e->reserve(n)) return st;
+    return logprob_dev(e, n, dP, dout, stream ? (hipStream_t)stream : e->stream, 0);
+}
+lcf_status lcf_log_posterior_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream) {
+    if (!e || n < 0 || (n > 0 && (!dP || !dout))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(e->device));
+    if (lcf_status st = e->reserve(n)) return st;
+    return logprob_dev(e, n, dP, dout, stream ? (hipStream_t)stream : e->stream, 1);
+}
+
+static lcf_status evaluate_impl(lcf_engine* e, int64_t n, const double* P, double* o0, double* o1, int mode) {
+    if (!e || n < 0 || (n > 0 && (!P || !o0 || (mode == 2 && !o1)))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0 || e->dp.n_points == 0) return LCF_OK;
+    LCF_HIP(hipSetDevice(e->device));
+    if (lcf_status st = e->reserve(n)) return st;
+    const size_t N = e->dp.n_points;
+    // bound the device scratch to ~256 MiB per pass
+    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)((256u << 20) / (N * sizeof(double) * (mode == 2 ? 2 : 1)))));
+    if (lcf_status st = e->reserve_big(per * N * sizeof(double) * (mode == 2 ? 2 : 1))) return st;
+    LCF_HIP(hipMemcpyAsync(e->wP, P, n * e->dp.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    const int bs = 128;
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, e->stream, e->dp, (int)n, e->wP,
+                       e->wcoef, e->wlprior, 0);
+    for (int64_t lo = 0; lo < n; lo += per) {
+        const int64_t m = std::min(per, n - lo);
+        double* b0 = e->wbig;
+        double* b1 = e->wbig + per * N;
+        if (mode == 1)
+            launch_points<1>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, b0, nullptr, e->stream);
+        else
+            launch_points<2>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, b0, b1, e->stream);
+        LCF_HIP(hipGetLastError());
+        LCF_HIP(hipMemcpyAsync(o0 + lo * N, b0, m * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (mode == 2) LCF_HIP(hipMemcpyAsync(o1 + lo * N, b1, m * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        LCF_HIP(hipStreamSynchronize(e->stream));
+    }
+    return LCF_OK;
+}
+
+lcf_status lcf_model_evaluate(lcf_engine* e, int64_t n, const double* P, double* y_fit) {
+    return evaluate_impl(e, n, P, y_fit, nullptr, 1);
+}
+lcf_status lcf_temperature_radius(lcf_engine* e, int64_t n, const double* P, double* T_K, double* R_bb) {
+    return evaluate_impl(e, n, P, T_K, R_bb, 2);
+}
+
+lcf_status lcf_blackbody_to_filters(lcf_engine* e, int64_t m, const int32_t* filt_idx, const double* T, const double* R,
+                                    double* out) {
+    if (!e || m < 0 || (m > 0 && (!filt_idx || !T || !R || !out))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (m == 0) return LCF_OK;
+    for (int64_t i = 0; i < m; ++i)
+        if (filt_idx[i] < 0 || filt_idx[i] >= e->dp.n_filters) return fail(LCF_ERR_INVALID_ARGUMENT, "filt_idx out of range");
+    LCF_HIP(hipSetDevice(e->device));
+    const size_t bytes = m * (3 * sizeof(double) + sizeof(int));
+    if (lcf_status st = e->reserve_big(bytes + 64)) return st;
+    double* dT = e->wbig;
+    double* dR = dT + m;
+    double* dO = dR + m;
+    int* dF = reinterpret_cast<int*>(dO + m);
+    LCF_HIP(hipMemcpyAsync(dT, T, m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    LCF_HIP(hipMemcpyAsync(dR, R, m * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    LCF_HIP(hipMemcpyAsync(dF, filt_idx, m * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
+    if (e->dp.variant == 0)
+        hipLaunchKernelGGL(k_bb_pointwise<0>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, dT, dR, dO);
+    else
+        hipLaunchKernelGGL(k_bb_pointwise<1>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, dT, dR, dO);
+    LCF_HIP(hipGetLastError());
+    LCF_HIP(hipMemcpyAsync(out, dO, m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    LCF_HIP(hipStreamSynchronize(e->stream));
+    return LCF_OK;
+}
+
+}  // extern "C"
+
+extern "C" lcf_status lcf_profile_loglike_kernel(lcf_engine* e, int64_t n, const double* P, int32_t reps,
+                                                 double* avg_ms) {
+    if (!e || n <= 0 || !P || reps <= 0 || !avg_ms) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    LCF_HIP(hipSetDevice(e->device));
+    if (lcf_status st = e->reserve(n)) return st;
+    LCF_HIP(hipMemcpyAsync(e->wP, P, n * e->dp.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->dp, (int)n, e->wP,
+                       e->wcoef, e->wlprior, 0);
+    launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wpart, nullptr, e->stream);  // warm-up
+    hipEvent_t a, b;
+    LCF_HIP(hipEventCreate(&a));
+    LCF_HIP(hipEventCreate(&b));
+    LCF_HIP(hipEventRecord(a, e->stream));
+    for (int r = 0; r < reps; ++r) launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wpart, nullptr, e->stream);
+    LCF_HIP(hipEventRecord(b, e->stream));
+    LCF_HIP(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    LCF_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    LCF_HIP(hipGetLastError());
+    *avg_ms = (double)ms / reps;
+    return LCF_OK;
+}
+
+// =================================================================================================================
+// sampler
+// =================================================================================================================
+struct lcf_sampler {
+    lcf_engine* e = nullptr;
+    DevSampler ds{};
+    std::vector<void*> owned;
+    double *coef = nullptr, *lprior = nullptr, *part = nullptr;
+    int* d_perm = nullptr;
+    int64_t perm_rows = 0;       // rows allocated
+    bool have_perm = false;
+    int64_t run_first = 0, run_steps = 0;
+    int64_t chain_cap = 0;
+    bool has_state = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.;
+
+    ~lcf_sampler() {
+        hipSetDevice(e->device);
+        for (void* p : owned) hipFree(p);
+        if (ds.chain) hipFree(ds.chain);
+        if (ds.chain_lp) hipFree(ds.chain_lp);
+        if (d_perm) hipFree(d_perm);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+    }
+};
+
+namespace {
+
+template <class T>
+lcf_status dalloc(T** p, size_t n, std::vector<void*>& owned) {
+    LCF_HIP(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    owned.push_back(*p);
+    return LCF_OK;
+}
+
+lcf_status sampler_half(lcf_sampler* s, int64_t step, int half, int lo, int hi, hipStream_t st, bool do_propose,
+                        bool do_eval, bool do_accept) {
+    lcf_engine* e = s->e;
+    const DevSampler& ds = s->ds;
+    const int nh = ds.n_half, bs = 128;
+    const int64_t row = step - s->run_first;
+    const int* perm = s->have_perm ? s->d_perm + (size_t)row * ds.n_walkers : nullptr;
+    if (do_propose)
+        hipLaunchKernelGGL(k_propose, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, e->dp, ds, perm, (long long)step,
+                           (long long)row, half, s->coef, s->lprior);
+    if (do_eval && hi > lo) {
+        launch_points<0>(e, lo, hi - lo, ds.Q, s->coef, s->lprior, s->part, nullptr, st);
+        hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
+                           s->part + (size_t)lo * e->dp.n_chunks, s->lprior + lo, ds.newlp + lo);
+    }
+    if (do_accept)
+        hipLaunchKernelGGL(k_accept, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, ds, (long long)row);
+    LCF_HIP(hipGetLastError());
+    return LCF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, double a, lcf_sampler** out) {
+    if (!e || !out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (n_walkers < 2 || (n_walkers & 1)) return fail(LCF_ERR_INVALID_ARGUMENT, "n_walkers must be even and >= 2");
+    if (!(a > 1.)) return fail(LCF_ERR_INVALID_ARGUMENT, "stretch scale a must be > 1");
+    LCF_HIP(hipSetDevice(e->device));
+    auto* s = new lcf_sampler();
+    s->e = e;
+    DevSampler& ds = s->ds;
+    ds.n_walkers = n_walkers;
+    ds.n_half = n_walkers / 2;
+    ds.n_dim = e->dp.n_dim;
+    ds.key0 = (uint32_t)(seed & 0xffffffffu);
+    ds.key1 = (uint32_t)(seed >> 32);
+    ds.a = a;
+    const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
+    lcf_status st;
+#define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
+    AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.Q, nh * nd); AL(ds.zl, nh); AL(ds.lnu, nh); AL(ds.act, nh);
+    AL(ds.newlp, nh); AL(ds.nacc, nw); AL(ds.err, 1);
+    AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_chunks);
+#undef AL
+    hipMemset(ds.nacc, 0, nw * sizeof(long long));
+    hipMemset(ds.err, 0, sizeof(int));
+    hipEventCreate(&s->ev0);
+    hipEventCreate(&s->ev1);
+    *out = s;
+    return LCF_OK;
+}
+
+void lcf_sampler_destroy(lcf_sampler* s) { delete s; }
+
+lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
+    if (!s || !coords) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    lcf_engine* e = s->e;
+    LCF_HIP(hipSetDevice(e->device));
+    const DevSampler& ds = s->ds;
+    if (lcf_status st = e->reserve(ds.n_walkers)) return st;
+    LCF_HIP(hipMemcpyAsync(ds.X, coords, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (lcf_status st = logprob_dev(e, ds.n_walkers, ds.X, ds.LP, e->stream, 1)) return st;
+    LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
+    LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
+    LCF_HIP(hipStreamSynchronize(e->stream));
+    s->has_state = true;
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_get_state(lcf_sampler* s, double* coords, double* log_prob) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    const DevSampler& ds = s->ds;
+    if (coords) LCF_HIP(hipMemcpy(coords, ds.X, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
+    if (log_prob) LCF_HIP(hipMemcpy(log_prob, ds.LP, (size_t)ds.n_walkers * sizeof(double), hipMemcpyDeviceToHost));
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                             const int32_t* perm, int32_t store_chain) {
+    if (!s || n_steps < 0 || first_step < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    if (split_mode < LCF_SPLIT_IDENTITY || split_mode > LCF_SPLIT_HOST)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad split_mode");
+    if (split_mode == LCF_SPLIT_HOST && !perm && n_steps > 0)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "LCF_SPLIT_HOST needs perm");
+    if (split_mode == LCF_SPLIT_RANDOM && s->ds.n_walkers > 16384)
+        return fail(LCF_ERR_UNSUPPORTED, "device-generated splits support at most 16384 walkers; pass perm");
+    if (split_mode != LCF_SPLIT_HOST) perm = nullptr;
+    if (!s->has_state) return fail(LCF_ERR_STATE, "lcf_sampler_set_state must be called first");
+    lcf_engine* e = s->e;
+    LCF_HIP(hipSetDevice(e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    DevSampler& ds = s->ds;
+    s->run_first = first_step;
+    s->run_steps = n_steps;
+    ds.store_chain = store_chain ? 1 : 0;
+    if (store_chain && n_steps > s->chain_cap) {
+        if (ds.chain) hipFree(ds.chain);
+        if (ds.chain_lp) hipFree(ds.chain_lp);
+        ds.chain = nullptr;
+        ds.chain_lp = nullptr;
+        s->chain_cap = 0;
+        LCF_HIP(hipMalloc((void**)&ds.chain, (size_t)n_steps * ds.n_walkers * ds.n_dim * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&ds.chain_lp, (size_t)n_steps * ds.n_walkers * sizeof(double)));
+        s->chain_cap = n_steps;
+    }
+    s->have_perm = split_mode != LCF_SPLIT_IDENTITY;
+    if (s->have_perm && n_steps > 0) {
+        if (n_steps > s->perm_rows) {
+            if (s->d_perm) hipFree(s->d_perm);
+            s->d_perm = nullptr;
+            s->perm_rows = 0;
+            LCF_HIP(hipMalloc((void**)&s->d_perm, (size_t)n_steps * ds.n_walkers * sizeof(int)));
+            s->perm_rows = n_steps;
+        }
+    }
+    if (split_mode == LCF_SPLIT_RANDOM && n_steps > 0) {
+        int n_pad = 2;
+        while (n_pad < ds.n_walkers) n_pad <<= 1;
+        const int threads = std::min(1024, std::max(64, n_pad / 2));
+        if ((size_t)n_pad * 8 > 65536)
+            LCF_HIP(hipFuncSetAttribute((const void*)k_make_perm, hipFuncAttributeMaxDynamicSharedMemorySize, n_pad * 8));
+        hipLaunchKernelGGL(k_make_perm, dim3((unsigned)n_steps), dim3(threads), (size_t)n_pad * 8, e->stream,
+                           ds.n_walkers, n_pad, ds.key0, ds.key1, (long long)first_step, s->d_perm);
+        LCF_HIP(hipGetLastError());
+        LCF_HIP(hipStreamSynchronize(e->stream));
+    }
+    if (perm && n_steps > 0) {
+        // validate: every row must be a permutation of 0..n_walkers-1 (out-of-range ids would fault the GPU)
+        std::vector<char> seen(ds.n_walkers);
+        for (int64_t r = 0; r < n_steps; ++r) {
+            std::fill(seen.begin(), seen.end(), 0);
+            const int32_t* row = perm + (size_t)r * ds.n_walkers;
+            for (int i = 0; i < ds.n_walkers; ++i) {
+                if (row[i] < 0 || row[i] >= ds.n_walkers || seen[row[i]])
+                    return fail(LCF_ERR_INVALID_ARGUMENT, "perm rows must be permutations of the walker ids");
+                seen[row[i]] = 1;
+            }
+        }
+        LCF_HIP(hipMemcpy(s->d_perm, perm, (size_t)n_steps * ds.n_walkers * sizeof(int), hipMemcpyHostToDevice));
+    }
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void* stream) {
+    if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
+    return sampler_half(s, step, half, 0, 0, stream ? (hipStream_t)stream : s->e->stream, true, false, false);
+}
+lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
+    if (!s || lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
+    return sampler_half(s, s->run_first, 0, lo, hi, stream ? (hipStream_t)stream : s->e->stream, false, true, false);
+}
+lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* stream) {
+    if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
+    return sampler_half(s, step, half, 0, 0, stream ? (hipStream_t)stream : s->e->stream, false, false, true);
+}
+void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp : nullptr; }
+
+lcf_status lcf_sampler_check(lcf_sampler* s) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    int err = 0;
+    LCF_HIP(hipMemcpy(&err, s->ds.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                           const int32_t* perm, int32_t store_chain) {
+    if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
+    hipStream_t st = s->e->stream;
+    LCF_HIP(hipEventRecord(s->ev0, st));
+    for (int64_t k = 0; k < n_steps; ++k)
+        for (int half = 0; half < 2; ++half)
+            if (lcf_status r = sampler_half(s, first_step + k, half, 0, s->ds.n_half, st, true, true, true)) return r;
+    LCF_HIP(hipEventRecord(s->ev1, st));
+    LCF_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    LCF_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->last_ms = ms;
+    return lcf_sampler_check(s);
+}
+
+lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!s->ds.store_chain || s->run_steps == 0) return fail(LCF_ERR_STATE, "no stored chain");
+    LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    const DevSampler& ds = s->ds;
+    if (chain)
+        LCF_HIP(hipMemcpy(chain, ds.chain, (size_t)s->run_steps * ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
+    if (log_prob)
+        LCF_HIP(hipMemcpy(log_prob, ds.chain_lp, (size_t)s->run_steps * ds.n_walkers * sizeof(double), hipMemcpyDeviceToHost));
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted) {
+    if (!s || !n_accepted) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    LCF_HIP(hipMemcpy(n_accepted, s->ds.nacc, (size_t)s->ds.n_walkers * sizeof(long long), hipMemcpyDeviceToHost));
+    return LCF_OK;
+}
+
+double lcf_sampler_last_run_ms(const lcf_sampler* s) { return s ? s->last_ms : 0.; }
+
+}  // extern "C"

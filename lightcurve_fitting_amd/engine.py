@@ -1,0 +1,333 @@
+"""ctypes binding of the C ABI in ``include/lcf.h`` (``csrc/liblcf_hip.so``, built for gfx950).
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is visible, constructing an
+:class:`Engine` raises.  Host-side work here is limited to marshalling (contiguous float64 blocks in, arrays out).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
+
+LCF_ABI_VERSION = 1
+N_CONSTS = 12
+
+MODEL_SHOCK_COOLING = 1
+MODEL_SHOCK_COOLING2 = 2
+MODEL_SHOCK_COOLING4 = 4
+MODEL_COMPANION_SHOCKING = 5
+MODEL_COMPANION_SHOCKING2 = 6
+MODEL_COMPANION_SHOCKING3 = 7
+MODEL_BLACKBODY = 8
+
+PRIOR_UNIFORM, PRIOR_LOG_UNIFORM, PRIOR_GAUSSIAN = 0, 1, 2
+SIGMA_RELATIVE, SIGMA_ABSOLUTE = 0, 1
+SPLIT_IDENTITY, SPLIT_RANDOM, SPLIT_HOST = 0, 1, 2
+
+STATUS_NAMES = {0: 'LCF_OK', 1: 'LCF_ERR_INVALID_ARGUMENT', 2: 'LCF_ERR_HIP', 3: 'LCF_ERR_NO_DEVICE',
+                4: 'LCF_ERR_OUT_OF_MEMORY', 5: 'LCF_ERR_UNSUPPORTED', 6: 'LCF_ERR_NAN_LOGPROB', 7: 'LCF_ERR_STATE'}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class LcfPrior(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('p_min', C.c_double), ('p_max', C.c_double),
+                ('mean', C.c_double), ('stddev', C.c_double)]
+
+
+class LcfProblem(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('model', C.c_int32), ('n_par', C.c_int32), ('use_sigma', C.c_int32),
+                ('sigma_type', C.c_int32), ('n_filters', C.c_int32), ('n_points', C.c_int64),
+                ('consts', C.c_double * N_CONSTS),
+                ('t', _dp), ('y', _dp), ('dy', _dp), ('filt_idx', _ip), ('tab_off', _ip), ('tab_a', _dp),
+                ('tab_w', _dp), ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
+                ('n_knots', C.c_int32), ('reserved', C.c_int32), ('spline_knots', _dp), ('spline_coef', _dp),
+                ('priors', C.POINTER(LcfPrior))]
+
+
+class LcfError(RuntimeError):
+    """A non-zero ``lcf_status`` from the native library."""
+
+    def __init__(self, status, message):
+        self.status = status
+        super().__init__(f'{STATUS_NAMES.get(status, status)}: {message}')
+
+
+_lib = None
+
+#: every symbol include/lcf.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ('lcf_abi_version', C.c_int32, []),
+    ('lcf_last_error', C.c_char_p, []),
+    ('lcf_device_count', C.c_int32, []),
+    ('lcf_engine_create', C.c_int, [C.POINTER(LcfProblem), C.c_int32, C.POINTER(C.c_void_p)]),
+    ('lcf_engine_destroy', None, [C.c_void_p]),
+    ('lcf_engine_ndim', C.c_int32, [C.c_void_p]),
+    ('lcf_engine_npoints', C.c_int64, [C.c_void_p]),
+    ('lcf_engine_samples_per_eval', C.c_int64, [C.c_void_p]),
+    ('lcf_engine_set_variant', C.c_int, [C.c_void_p, C.c_int32]),
+    ('lcf_log_likelihood', C.c_int, [C.c_void_p, C.c_int64, _dp, _dp]),
+    ('lcf_log_posterior', C.c_int, [C.c_void_p, C.c_int64, _dp, _dp]),
+    ('lcf_log_likelihood_dev', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('lcf_log_posterior_dev', C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('lcf_model_evaluate', C.c_int, [C.c_void_p, C.c_int64, _dp, _dp]),
+    ('lcf_temperature_radius', C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp]),
+    ('lcf_blackbody_to_filters', C.c_int, [C.c_void_p, C.c_int64, _ip, _dp, _dp, _dp]),
+    ('lcf_profile_loglike_kernel', C.c_int, [C.c_void_p, C.c_int64, _dp, C.c_int32, _dp]),
+    ('lcf_sampler_create', C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_double, C.POINTER(C.c_void_p)]),
+    ('lcf_sampler_destroy', None, [C.c_void_p]),
+    ('lcf_sampler_set_state', C.c_int, [C.c_void_p, _dp]),
+    ('lcf_sampler_get_state', C.c_int, [C.c_void_p, _dp, _dp]),
+    ('lcf_sampler_run', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_get_chain', C.c_int, [C.c_void_p, _dp, _dp]),
+    ('lcf_sampler_get_naccepted', C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ('lcf_sampler_last_run_ms', C.c_double, [C.c_void_p]),
+    ('lcf_sampler_begin', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_propose', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    ('lcf_sampler_evaluate', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ('lcf_sampler_accept', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
+    ('lcf_sampler_check', C.c_int, [C.c_void_p]),
+]
+
+
+def load_library(path=None):
+    """dlopen the native library and attach prototypes.  Raises ``OSError`` with build instructions if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+                      f'`make -C {os.path.dirname(path)}` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(path)
+    for name, restype, argtypes in SIGNATURES:
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lcf_abi_version() != LCF_ABI_VERSION:
+        raise OSError(f'{path}: ABI version {lib.lcf_abi_version()} != {LCF_ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != 0:
+        raise LcfError(status, load_library().lcf_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a, typ=_dp):
+    return a.ctypes.data_as(typ)
+
+
+class Engine:
+    """One light curve + one model instance resident on one MI355X.
+
+    Parameters are the fields of ``lcf_problem`` (see ``include/lcf.h``): ``priors`` is a sequence of
+    ``(kind, p_min, p_max, mean, stddev)`` or ``None``."""
+
+    def __init__(self, model_id, n_par, consts, t, y, dy, filt_idx, tab_off, tab_a, tab_w, use_sigma=False,
+                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0):
+        lib = load_library()
+        self._lib = lib
+        self._h = C.c_void_p()
+        keep = [_f64(t), _f64(y), _f64(dy), _i32(filt_idx), _i32(tab_off), _f64(tab_a), _f64(tab_w)]
+        pr = LcfProblem()
+        pr.abi_version = LCF_ABI_VERSION
+        pr.model = int(model_id)
+        pr.n_par = int(n_par)
+        pr.use_sigma = int(bool(use_sigma))
+        pr.sigma_type = int(sigma_type)
+        pr.n_filters = len(keep[4]) - 1
+        pr.n_points = len(keep[0])
+        if not (len(keep[1]) == len(keep[2]) == len(keep[3]) == pr.n_points):
+            raise ValueError('t, y, dy, filt_idx must have the same length')
+        cs = list(consts) + [0.] * (N_CONSTS - len(consts))
+        pr.consts = (C.c_double * N_CONSTS)(*cs)
+        pr.t, pr.y, pr.dy = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
+        pr.filt_idx, pr.tab_off = _ptr(keep[3], _ip), _ptr(keep[4], _ip)
+        pr.tab_a, pr.tab_w = _ptr(keep[5]), _ptr(keep[6])
+        if companion is not None:
+            kp, sp, dtp, knots, coef = companion
+            extra = [_i32(kp), _i32(sp), _i32(dtp), _f64(knots), _f64(coef)]
+            if extra[4].shape != (pr.n_filters, len(extra[3]) - 1, 4):
+                raise ValueError('spline_coef must have shape (n_filters, n_knots - 1, 4)')
+            keep += extra
+            pr.filt_kasen_par, pr.filt_sifto_par, pr.filt_dt_par = (_ptr(x, _ip) for x in extra[:3])
+            pr.n_knots = len(extra[3])
+            pr.spline_knots, pr.spline_coef = _ptr(extra[3]), _ptr(extra[4])
+        n_dim = pr.n_par + pr.use_sigma
+        if priors is not None:
+            if len(priors) != n_dim:
+                raise ValueError(f'priors must have length {n_dim}')
+            arr = (LcfPrior * n_dim)()
+            for i, (kind, lo, hi, mean, std) in enumerate(priors):
+                arr[i].kind, arr[i].p_min, arr[i].p_max, arr[i].mean, arr[i].stddev = int(kind), lo, hi, mean, std
+            keep.append(arr)
+            pr.priors = arr
+        _check(lib.lcf_engine_create(C.byref(pr), int(device), C.byref(self._h)))
+        self.ndim = n_dim
+        self.npoints = pr.n_points
+        self.device = int(device)
+        self.samples_per_eval = lib.lcf_engine_samples_per_eval(self._h)
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.lcf_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_variant(self, variant):
+        _check(self._lib.lcf_engine_set_variant(self._h, int(variant)))
+
+    def _block(self, P):
+        P = _f64(P)
+        if P.ndim == 1:
+            P = P[None, :]
+        if P.ndim != 2 or P.shape[1] != self.ndim:
+            raise ValueError(f'parameter block must have shape (n, {self.ndim}), got {P.shape}')
+        return P
+
+    def log_likelihood(self, P):
+        P = self._block(P)
+        out = np.empty(len(P))
+        _check(self._lib.lcf_log_likelihood(self._h, len(P), _ptr(P), _ptr(out)))
+        return out
+
+    def log_posterior(self, P):
+        P = self._block(P)
+        out = np.empty(len(P))
+        _check(self._lib.lcf_log_posterior(self._h, len(P), _ptr(P), _ptr(out)))
+        return out
+
+    def log_likelihood_dev(self, n, dP, dout, stream=0, posterior=False):
+        """Device pointers (ints), enqueue only."""
+        fn = self._lib.lcf_log_posterior_dev if posterior else self._lib.lcf_log_likelihood_dev
+        _check(fn(self._h, int(n), C.c_void_p(dP), C.c_void_p(dout), C.c_void_p(stream)))
+
+    def evaluate(self, P):
+        P = self._block(P)
+        out = np.empty((len(P), self.npoints))
+        _check(self._lib.lcf_model_evaluate(self._h, len(P), _ptr(P), _ptr(out)))
+        return out
+
+    def temperature_radius(self, P):
+        P = self._block(P)
+        T = np.empty((len(P), self.npoints))
+        R = np.empty((len(P), self.npoints))
+        _check(self._lib.lcf_temperature_radius(self._h, len(P), _ptr(P), _ptr(T), _ptr(R)))
+        return T, R
+
+    def profile_loglike_kernel(self, P, reps=20):
+        """Average duration [ms] of the per-point likelihood kernel alone (HIP events, engine stream)."""
+        P = self._block(P)
+        ms = C.c_double()
+        _check(self._lib.lcf_profile_loglike_kernel(self._h, len(P), _ptr(P), int(reps), C.byref(ms)))
+        return ms.value
+
+    def blackbody_to_filters(self, filt_idx, T, R):
+        f, T, R = _i32(filt_idx), _f64(T), _f64(R)
+        if not (f.shape == T.shape == R.shape and f.ndim == 1):
+            raise ValueError('filt_idx, T and R must be 1-D and of equal length')
+        out = np.empty(len(f))
+        _check(self._lib.lcf_blackbody_to_filters(self._h, len(f), _ptr(f, _ip), _ptr(T), _ptr(R), _ptr(out)))
+        return out
+
+
+class NativeSampler:
+    """Thin handle on ``lcf_sampler`` (device-resident stretch move)."""
+
+    def __init__(self, engine, nwalkers, seed=0, a=2.0):
+        self._lib = engine._lib
+        self.engine = engine
+        self.nwalkers = int(nwalkers)
+        self.ndim = engine.ndim
+        self._h = C.c_void_p()
+        _check(self._lib.lcf_sampler_create(engine.handle, self.nwalkers, C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                            float(a), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.lcf_sampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_state(self, coords):
+        coords = _f64(coords)
+        if coords.shape != (self.nwalkers, self.ndim):
+            raise ValueError(f'coords must have shape ({self.nwalkers}, {self.ndim})')
+        _check(self._lib.lcf_sampler_set_state(self._h, _ptr(coords)))
+
+    def get_state(self):
+        x = np.empty((self.nwalkers, self.ndim))
+        lp = np.empty(self.nwalkers)
+        _check(self._lib.lcf_sampler_get_state(self._h, _ptr(x), _ptr(lp)))
+        return x, lp
+
+    @staticmethod
+    def _split(split, nsteps, nwalkers):
+        """``split``: 'random' (device-generated, emcee's randomize_split), 'identity', or an int32 array
+        (nsteps, nwalkers) of host-provided permutations."""
+        if isinstance(split, str):
+            return {'identity': SPLIT_IDENTITY, 'random': SPLIT_RANDOM}[split], None, None
+        perm = _i32(split)
+        if perm.shape != (nsteps, nwalkers):
+            raise ValueError(f'perm must have shape ({nsteps}, {nwalkers})')
+        return SPLIT_HOST, perm, _ptr(perm, _ip)
+
+    def run(self, first_step, nsteps, split='random', store=True):
+        mode, keep, pp = self._split(split, nsteps, self.nwalkers)
+        _check(self._lib.lcf_sampler_run(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
+        self._last = (int(nsteps), bool(store))
+
+    def begin(self, first_step, nsteps, split='random', store=True):
+        mode, keep, pp = self._split(split, nsteps, self.nwalkers)
+        _check(self._lib.lcf_sampler_begin(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
+        self._last = (int(nsteps), bool(store))
+
+    def propose(self, step, half, stream=0):
+        _check(self._lib.lcf_sampler_propose(self._h, int(step), int(half), C.c_void_p(stream)))
+
+    def evaluate(self, lo, hi, stream=0):
+        _check(self._lib.lcf_sampler_evaluate(self._h, int(lo), int(hi), C.c_void_p(stream)))
+
+    def accept(self, step, half, stream=0):
+        _check(self._lib.lcf_sampler_accept(self._h, int(step), int(half), C.c_void_p(stream)))
+
+    def newlp_ptr(self):
+        return self._lib.lcf_sampler_newlp_ptr(self._h)
+
+    def check(self):
+        _check(self._lib.lcf_sampler_check(self._h))
+
+    def get_chain(self):
+        nsteps, store = self._last
+        chain = np.empty((nsteps, self.nwalkers, self.ndim))
+        lp = np.empty((nsteps, self.nwalkers))
+        _check(self._lib.lcf_sampler_get_chain(self._h, _ptr(chain), _ptr(lp)))
+        return chain, lp
+
+    def naccepted(self):
+        out = np.empty(self.nwalkers, dtype=np.int64)
+        _check(self._lib.lcf_sampler_get_naccepted(self._h, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def last_run_ms(self):
+        return float(self._lib.lcf_sampler_last_run_ms(self._h))

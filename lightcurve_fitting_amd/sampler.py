@@ -1,0 +1,254 @@
+"""Ensemble sampler driver with the surface of ``emcee.EnsembleSampler`` that ``lightcurve_mcmc`` and its
+consumers use (reference fitting.py:130-148, 171-277): ``run_mcmc``, ``reset``, ``chain``, ``flatchain``,
+``lnprobability``/``get_log_prob``, ``acceptance_fraction``.
+
+The stretch move itself (Goodman & Weare 2010, red/blue halves, a = 2) runs on the GPU
+(``lcf_sampler_*`` in ``include/lcf.h``):
+
+* single GPU: the whole run is enqueued by one native call, no host round-trip per step;
+* several GPUs (``torch.distributed`` initialised, one process per GPU): every rank holds the full ensemble,
+  proposals and accept/reject are replicated from the same counter-based RNG, each rank evaluates the likelihood of
+  its contiguous shard of the active half, and ONE all-gather of ``n_walkers/2`` float64 log-probabilities per
+  half-step (RCCL over xGMI; latency-bound, <= 16 KiB) makes the ranks agree.  Chains are therefore identical for
+  any number of GPUs.
+
+The per-half-step protocol is factored into :class:`ShardedStretchDriver` over a small backend interface so that
+the multi-rank logic can be exercised on CPU with ``gloo`` (tests inject a checker backend there).
+"""
+import numpy as np
+
+from . import rng as _rng
+
+
+class State(tuple):
+    """``(coords, log_prob, random_state)`` -- unpacks like emcee's ``State`` (fitting.py:133)."""
+
+    def __new__(cls, coords, log_prob, random_state=None):
+        return super().__new__(cls, (coords, log_prob, random_state))
+
+    coords = property(lambda self: self[0])
+    log_prob = property(lambda self: self[1])
+    random_state = property(lambda self: self[2])
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous, balanced partition of ``range(n_items)``: returns ``(lo, hi, width)`` with ``width`` the padded
+    per-rank slot size used by the all-gather."""
+    width = -(-n_items // world_size)
+    lo = min(rank * width, n_items)
+    hi = min(lo + width, n_items)
+    return lo, hi, width
+
+
+class NativeBackend:
+    """Backend over ``lcf_sampler``: device buffers live in the native library; the collective sees them as torch
+    tensors through ``__cuda_array_interface__`` (no copy)."""
+
+    def __init__(self, native_sampler):
+        self.ns = native_sampler
+        self.n_half = native_sampler.nwalkers // 2
+        self._newlp = None
+
+    def begin(self, first_step, nsteps, split, store):
+        self.ns.begin(first_step, nsteps, split, store)
+
+    def stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def propose(self, step, half):
+        self.ns.propose(step, half, self.stream())
+
+    def evaluate(self, lo, hi):
+        self.ns.evaluate(lo, hi, self.stream())
+
+    def accept(self, step, half):
+        self.ns.accept(step, half, self.stream())
+
+    def newlp(self):
+        """float64 torch tensor aliasing the native ``newlp[n_half]`` buffer."""
+        if self._newlp is None:
+            import torch
+            ptr, n = self.ns.newlp_ptr(), self.n_half
+
+            class _Alias:
+                __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2,
+                                            'strides': None}
+            self._newlp = torch.as_tensor(_Alias(), device=f'cuda:{self.ns.engine.device}')
+        return self._newlp
+
+    def empty(self, n):
+        import torch
+        return torch.empty(n, dtype=torch.float64, device=f'cuda:{self.ns.engine.device}')
+
+    def finish(self):
+        self.ns.check()
+
+
+class ShardedStretchDriver:
+    """Runs half-steps over a backend, sharding the likelihood evaluation over the ranks of a process group."""
+
+    def __init__(self, backend, group=None):
+        import torch.distributed as dist
+        self.backend = backend
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi, self.width = shard_bounds(backend.n_half, self.world, self.rank)
+        if self.world > 1:
+            self._send = backend.empty(self.width)
+            self._recv = backend.empty(self.width * self.world)
+
+    def run(self, first_step, nsteps, split, store):
+        """``split``: 'random' | 'identity' | int32 array (nsteps, nwalkers), see ``NativeSampler._split``."""
+        b = self.backend
+        b.begin(first_step, nsteps, split, store)
+        for k in range(nsteps):
+            step = first_step + k
+            for half in (0, 1):
+                b.propose(step, half)
+                b.evaluate(self.lo, self.hi)
+                if self.world > 1:
+                    newlp = b.newlp()
+                    n = self.hi - self.lo
+                    if n:
+                        self._send[:n].copy_(newlp[self.lo:self.hi])
+                    self.dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
+                    for r in range(self.world):  # unpad: rank r owns [r*width, min((r+1)*width, n_half))
+                        lo, hi, _ = shard_bounds(b.n_half, self.world, r)
+                        if hi > lo and r != self.rank:
+                            newlp[lo:hi].copy_(self._recv[r * self.width:r * self.width + (hi - lo)])
+                b.accept(step, half)
+        b.finish()
+
+
+class EnsembleSampler:
+    """Drop-in for the subset of ``emcee.EnsembleSampler`` the reference uses, bound to one engine.
+
+    Parameters
+    ----------
+    nwalkers, ndim : int
+    engine : lightcurve_fitting_amd.engine.Engine
+        Device engine whose log-posterior is sampled (priors baked in at engine creation).
+    seed : int
+        Key of the counter-based RNG (emcee uses NumPy's global state instead; sampler parity is statistical).
+    a : float
+        Stretch scale (emcee default 2.0).
+    randomize_split : bool
+        Fresh random red/blue colouring every step, as emcee's ``RedBlueMove`` does.
+    """
+
+    def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None):
+        from .engine import NativeSampler
+        if nwalkers % 2 or nwalkers < 2 * ndim:
+            raise ValueError('nwalkers must be even and at least 2 * ndim (emcee requirement)')
+        if ndim != engine.ndim:
+            raise ValueError(f'ndim = {ndim} but the engine has {engine.ndim} parameters')
+        self.nwalkers, self.ndim = nwalkers, ndim
+        self.engine = engine
+        self.seed = int(seed)
+        self.randomize_split = randomize_split
+        self._native = NativeSampler(engine, nwalkers, seed, a)
+        self._group = group
+        self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
+        self._chain = np.empty((0, nwalkers, ndim))
+        self._lp = np.empty((0, nwalkers))
+        self._naccepted = np.zeros(nwalkers, dtype=np.int64)
+        self._state = None
+
+    def _distributed(self):
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return False
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+
+    # --- emcee surface -------------------------------------------------------------------------------------------
+    def reset(self):
+        """Forget the stored chain (not the RNG position), like ``emcee.EnsembleSampler.reset``."""
+        self._chain = np.empty((0, self.nwalkers, self.ndim))
+        self._lp = np.empty((0, self.nwalkers))
+        self._naccepted[:] = 0
+
+    def run_mcmc(self, initial_state, nsteps, progress=False, progress_kwargs=None, skip_initial_state_check=False,
+                 store=True, **kwargs):
+        if initial_state is not None:
+            coords = np.array(initial_state[0] if isinstance(initial_state, tuple) else initial_state,
+                              dtype=np.float64)
+            if coords.shape != (self.nwalkers, self.ndim):
+                raise ValueError('incompatible input dimensions')
+            if not np.all(np.isfinite(coords)):
+                raise ValueError('At least one parameter value was infinite or NaN')
+            if not skip_initial_state_check and np.linalg.matrix_rank(coords - coords.mean(0)) < self.ndim:
+                raise ValueError('Initial state has a large condition number. '
+                                 'Make sure that your walkers are linearly independent for the best performance')
+            self._native.set_state(coords)
+            self._acc0 = np.zeros(self.nwalkers, dtype=np.int64)
+        elif self._state is None:
+            raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
+        else:
+            self._acc0 = self._native.naccepted()
+        if initial_state is not None and np.any(np.isnan(self._native.get_state()[1])):
+            raise ValueError('Probability function returned NaN')
+        split = 'random' if self.randomize_split else 'identity'
+        if self.randomize_split and self.nwalkers > 16384:  # beyond the device sort: host-generated colouring
+            split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
+        try:
+            if self._distributed():
+                ShardedStretchDriver(NativeBackend(self._native), self._group).run(self._steps_done, nsteps, split,
+                                                                                  store)
+            else:
+                self._native.run(self._steps_done, nsteps, split, store)
+        except Exception as exc:
+            if getattr(exc, 'status', None) == 6:
+                raise ValueError('Probability function returned NaN') from None
+            raise
+        self._steps_done += nsteps
+        if store and nsteps:
+            chain, lp = self._native.get_chain()
+            self._chain = np.concatenate([self._chain, chain])
+            self._lp = np.concatenate([self._lp, lp])
+        self._naccepted += self._native.naccepted() - self._acc0
+        x, lp = self._native.get_state()
+        self._state = State(x, lp, None)
+        return self._state
+
+    def get_chain(self, flat=False, thin=1, discard=0):
+        c = self._chain[discard::thin]
+        return c.reshape(-1, self.ndim) if flat else c
+
+    def get_log_prob(self, flat=False, thin=1, discard=0):
+        lp = self._lp[discard::thin]
+        return lp.reshape(-1) if flat else lp
+
+    @property
+    def chain(self):
+        """(nwalkers, nsteps, ndim), as emcee's deprecated-but-used ``.chain`` (fitting.py:139, 152)."""
+        return np.swapaxes(self._chain, 0, 1)
+
+    @property
+    def flatchain(self):
+        """(nwalkers * nsteps, ndim), walker-major like emcee's ``.flatchain`` (fitting.py:147, 203)."""
+        s = self.chain.shape
+        return self.chain.reshape(s[0] * s[1], s[2])
+
+    @property
+    def lnprobability(self):
+        return self._lp.T
+
+    @property
+    def flatlnprobability(self):
+        return self.lnprobability.reshape(-1)
+
+    @property
+    def iteration(self):
+        return len(self._chain)
+
+    @property
+    def acceptance_fraction(self):
+        return self._naccepted / max(1, self.iteration)
+
+    @property
+    def last_run_ms(self):
+        return self._native.last_run_ms()

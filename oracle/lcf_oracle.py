@@ -400,9 +400,9 @@ def philox4x32(counter, key):
 
 
 def u01(hi, lo):
-    """53-bit uniform in (0, 1) from two uint32 words: ((hi << 21) ^ (lo >> 11) + 0.5) * 2^-53."""
-    v = (np.asarray(hi, dtype=np.uint64) << np.uint64(21)) ^ (np.asarray(lo, dtype=np.uint64) >> np.uint64(11))
-    return (v.astype(np.float64) + 0.5) * (1. / 9007199254740992.)
+    """Uniform in (0, 1) from two uint32 words: 52 random bits plus one half, exactly representable."""
+    v = (np.asarray(hi, dtype=np.uint64) << np.uint64(20)) ^ (np.asarray(lo, dtype=np.uint64) >> np.uint64(12))
+    return (v.astype(np.float64) + 0.5) * (1. / 4503599627370496.)
 
 
 def stretch_draws(seed, step, half, walker_ids, n_other, a=2.):
@@ -423,11 +423,11 @@ def stretch_draws(seed, step, half, walker_ids, n_other, a=2.):
 
 def split_permutation(seed, step, nwalkers):
     """Random red/blue colouring of a step (emcee's ``randomize_split``): a permutation of walker ids whose first
-    half is colour 0.  Walkers are ranked by a Philox key; ties (probability ~2^-64) break by walker id."""
+    half is colour 0.  Walkers are ranked by 50 random Philox bits, ties broken by walker id."""
     wid = np.arange(nwalkers, dtype=np.uint64)
     r0, r1, _, _ = philox4x32((wid, np.full_like(wid, step), np.full_like(wid, 2), np.full_like(wid, 7)),
                               (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
-    keys = (r0.astype(np.uint64) << np.uint64(32)) | r1.astype(np.uint64)
+    keys = ((r0.astype(np.uint64) << np.uint64(32)) | r1.astype(np.uint64)) >> np.uint64(14)
     return np.lexsort((wid, keys))
 
 

@@ -1,0 +1,130 @@
+"""The device-resident stretch-move sampler against the CPU oracle sampler (same counter-based RNG) and by its
+statistics; ``lightcurve_mcmc`` end to end."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from helpers import lc_dict, oracle_log_posterior, small_problem
+from lightcurve_fitting_amd import models as M, rng
+from lightcurve_fitting_amd.fitting import lightcurve_mcmc
+from lightcurve_fitting_amd.sampler import EnsembleSampler
+from oracle import lcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nwalkers, seed=1):
+    pb = small_problem()
+    lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
+    m = M.ShockCooling(redshift=0.)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    eng = m.engine_for(lc, priors=priors)
+    r = np.random.default_rng(seed)
+    x0 = pb['truth'] * (1 + 0.05 * r.standard_normal((nwalkers, 5)))
+    return pb, lc, m, eng, x0
+
+
+@pytest.mark.parametrize('randomize', [True, False])
+def test_chain_matches_oracle_sampler(randomize):
+    pb, lc, m, eng, x0 = _setup(32)
+    s = EnsembleSampler(32, 5, eng, seed=987654321012345, randomize_split=randomize)
+    state = s.run_mcmc(x0, 12)
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 12, 987654321012345,
+                                              randomize_split=randomize)
+    # identical accept/reject decisions -> identical chains up to likelihood rounding (1e-14)
+    assert relerr(s.get_chain(), ref) < 1e-9
+    assert relerr(s.get_log_prob(), ref_lp) < 1e-9
+    assert np.array_equal(np.round(s.acceptance_fraction * 12).astype(int), ref_acc)
+    assert s.chain.shape == (32, 12, 5) and s.flatchain.shape == (32 * 12, 5)
+    assert np.array_equal(s.flatchain[:12], s.get_chain()[:, 0, :])  # walker-major flattening
+    coords, lp, _ = state
+    assert np.array_equal(coords, s.get_chain()[-1]) and np.array_equal(lp, s.get_log_prob()[-1])
+    # continuing from the stored state uses the next RNG steps
+    s.run_mcmc(None, 3)
+    ref2, _, _ = O.stretch_move_run(oracle_log_posterior(pb), ref[-1], 3, 987654321012345, log_prob0=ref_lp[-1],
+                                    randomize_split=randomize, first_step=12)
+    assert relerr(s.get_chain()[12:], ref2) < 1e-9
+    s.reset()
+    assert s.chain.shape == (32, 0, 5)
+
+
+def test_posterior_statistics_and_determinism():
+    pb, lc, m, eng, x0 = _setup(64)
+    a = EnsembleSampler(64, 5, eng, seed=5)
+    a.run_mcmc(x0, 300)
+    b = EnsembleSampler(64, 5, eng, seed=5)
+    b.run_mcmc(x0, 300)
+    assert np.array_equal(a.get_chain(), b.get_chain())  # bitwise reproducible
+    c = EnsembleSampler(64, 5, eng, seed=6)
+    c.run_mcmc(x0, 300)
+    assert not np.array_equal(a.get_chain(), c.get_chain())
+    flat = a.get_chain(discard=150, flat=True)
+    assert np.all(np.isfinite(flat))
+    # well-constrained combinations recover the truth: R (radius) and t_0
+    assert abs(np.median(flat[:, 4]) - pb['truth'][4]) < 0.1
+    assert 0.15 < a.acceptance_fraction.mean() < 0.8
+    assert a.last_run_ms > 0.
+
+
+def test_sampler_input_validation():
+    pb, lc, m, eng, x0 = _setup(32)
+    with pytest.raises(ValueError, match='nwalkers'):
+        EnsembleSampler(8, 5, eng)
+    with pytest.raises(ValueError, match='ndim'):
+        EnsembleSampler(32, 4, eng)
+    s = EnsembleSampler(32, 5, eng)
+    with pytest.raises(ValueError, match='dimensions'):
+        s.run_mcmc(x0[:10], 2)
+    with pytest.raises(ValueError, match='infinite or NaN'):
+        bad = x0.copy()
+        bad[0, 0] = np.nan
+        s.run_mcmc(bad, 2)
+    with pytest.raises(ValueError, match='linearly independent'):
+        s.run_mcmc(np.tile(x0[0], (32, 1)), 2)
+    with pytest.raises(ValueError, match='never been called'):
+        EnsembleSampler(32, 5, eng).run_mcmc(None, 2)
+    # NaN log-probability (R < 0 inside an unbounded prior) -> ValueError like emcee
+    m2 = M.ShockCooling(redshift=0.)
+    eng2 = m2.engine_for(lc)  # no priors
+    bad = x0.copy()
+    bad[:, 3] *= -1
+    with pytest.raises(ValueError, match='NaN'):
+        EnsembleSampler(32, 5, eng2).run_mcmc(bad, 2)
+
+
+def test_sharded_phases_equal_fused_run():
+    """propose / evaluate(shards) / accept called phase by phase reproduce lcf_sampler_run exactly."""
+    from lightcurve_fitting_amd.engine import NativeSampler
+    pb, lc, m, eng, x0 = _setup(32)
+    perm = rng.split_permutations(77, 0, 5, 32)
+    a = NativeSampler(eng, 32, 77)
+    a.set_state(x0)
+    a.run(0, 5, 'random', True)
+    b = NativeSampler(eng, 32, 77)
+    b.set_state(x0)
+    b.begin(0, 5, perm, True)  # host-provided colouring == device-generated colouring
+    for step in range(5):
+        for half in (0, 1):
+            b.propose(step, half)
+            for lo, hi in ((0, 5), (5, 11), (11, 16)):  # three uneven "ranks"
+                b.evaluate(lo, hi)
+            b.accept(step, half)
+    b.check()
+    assert np.array_equal(a.get_chain()[0], b.get_chain()[0])
+    assert np.array_equal(a.naccepted(), b.naccepted())
+
+
+def test_lightcurve_mcmc_end_to_end():
+    pb, lc, m, eng, x0 = _setup(32)
+    np.random.seed(3)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    lo = pb['truth'] * 0.8
+    hi = pb['truth'] * 1.2
+    sampler = lightcurve_mcmc(lc, m, priors=priors, p_lo=lo, p_up=hi, nwalkers=32, nsteps=40, nsteps_burnin=60)
+    assert sampler.chain.shape == (32, 40, 5) and sampler.flatchain.shape == (1280, 5)
+    assert np.all(sampler.flatchain[:, :4] > 0) and np.all(sampler.flatchain[:, :4] < 10)
+    m2 = M.ShockCooling(redshift=0.)
+    s2 = lightcurve_mcmc(lc, m2, priors=priors + [M.UniformPrior(0., 5.)], p_lo=np.append(lo, 0.1),
+                         p_up=np.append(hi, 1.), nwalkers=32, nsteps=10, nsteps_burnin=10, use_sigma=True,
+                         sigma_type='absolute')
+    assert s2.chain.shape == (32, 10, 6) and m2.input_names[-1] == '\\sigma'

@@ -1,0 +1,158 @@
+"""Host-side logic and the C-ABI surface.  CPU only: nothing here launches a kernel."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, relerr
+from lightcurve_fitting_amd import engine as E, filters as F, models as M, rng, sampler as S
+
+
+def test_filter_registry_matches_reference():
+    g = golden('filters')
+    assert [f.name for f in F.all_filters] == [str(x) for x in g['filt/order']]
+    alias = dict(zip([str(k) for k in g['filt/alias_keys']], [str(v) for v in g['filt/alias_vals']]))
+    assert {k: v.name for k, v in F.filtdict.items()} == alias
+    m0 = g['filt/M0_all']
+    mine = np.array([f.M0 for f in F.all_filters])
+    assert relerr(mine, m0) < 1e-15
+    for n, ch in zip(g['filt/names'], g['filt/chars']):
+        assert F.filtdict[str(n)].char == str(ch)
+
+
+def test_filter_curves_and_packed_tables():
+    g = golden('filters')
+    for n in g['filt/names']:
+        f = F.filtdict[str(n)]
+        assert relerr(f.freq, g[f'filt/{n}/freq']) < 1e-14
+        tn = g[f'filt/{n}/tnorm']
+        nz = tn != 0
+        assert relerr(f.T_norm_per_freq[nz], tn[nz]) < 1e-13 and np.all(f.T_norm_per_freq[~nz] == 0)
+        assert relerr([f.freq_eff, f.dfreq, f.M0, f.wl_eff, f.dwl], g[f'filt/{n}/scalars']) < 1e-13
+        a, w = f.planck_table(z=0.01)
+        assert np.all(w > 0) and np.all(a > 0) and len(a) <= f.nsamples
+    # packed (a, W) reproduces the reference band integral (computed here with plain NumPy from the tables)
+    p = golden('primitives')
+    names = [str(x) for x in p['synth/names']]
+    tabs = F.PackedTables(names, z=0.002)
+    for i, n in enumerate(names):
+        a, w = tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]]
+        mine = p['synth/R'] ** 2 * np.array([np.sum(w / np.expm1(a / t)) for t in p['synth/T']])
+        assert relerr(mine, p['synth/z0.002'][i]) < 1e-12
+    a, w = F.filtdict['g'].planck_table(z=0.01, cutoff_freq=300.)
+    mine = p['synth/R'] ** 2 * np.array([np.sum(w / np.expm1(a / t)) for t in p['synth/T']])
+    assert relerr(mine, p['synth/cutoff300_z0.01'][3]) < 1e-12
+    with pytest.raises(ValueError):
+        F.filtdict['L'].planck_table()
+    with pytest.raises(KeyError):
+        F.as_filter('no-such-filter')
+
+
+def test_not_a_knot_spline_matches_scipy_coefficients():
+    c = golden('companion')
+    lum = c['csb/lum']
+    names = [str(x) for x in c['csb/names']]
+    lc = {'MJD': c['csb/t'], 'filter': names, 'lum': lum, 'dlum': c['csb/dlum']}
+    m = M.CompanionShocking(lc, redshift=0.003)
+    for i, n in enumerate(c['csb/spline_filters']):
+        mine = m.sifto[F.filtdict[str(n)]]          # (n-1, 4)
+        ref = np.moveaxis(c['csb/spline_c'][i], 0, 1)  # scipy: (4, n-1)
+        scale = np.abs(ref).max()
+        assert np.max(np.abs(mine - ref)) / scale < 1e-12
+    with pytest.raises(Exception, match='No SiFTO template'):
+        M.CompanionShocking({'MJD': [1.], 'filter': ['z'], 'lum': [1.], 'dlum': [1.]})
+
+
+def test_priors():
+    p = golden('primitives')
+    xs = p['prior/x']
+    assert relerr(np.array([M.UniformPrior(0., 1.)(x) for x in xs], dtype=float), p['prior/uniform_0_1']) == 0
+    assert relerr(np.array([M.LogUniformPrior(0.01, 1000.)(x) for x in xs], dtype=float),
+                  p['prior/loguniform_0.01_1000']) < 1e-15
+    assert relerr(np.array([M.GaussianPrior(0., 10., 0., 1.)(x) for x in xs], dtype=float),
+                  p['prior/gaussian_0_10_0_1']) < 1e-15
+    with pytest.raises(ValueError):
+        M.LogUniformPrior(-1., 1.)
+    assert M.GaussianPrior(0., 10., 3., 2.).descriptor() == (2, 0., 10., 3., 2.)
+
+
+def test_model_metadata():
+    assert M.ShockCooling().nparams == 5 and M.ShockCooling2().nparams == 4 and M.ShockCooling4().nparams == 5
+    assert M.ShockCooling(n=3.).epsilon_T == pytest.approx(2 * 0.016 - 0.5)
+    assert M.ShockCooling(RW=True).a == 0. and M.ShockCooling(RW=True).Tph_to_Tcol == 1.2
+    with pytest.raises(ValueError, match='n can only be 1.5 or 3'):
+        M.ShockCooling(n=2.)
+    with pytest.raises(NotImplementedError):
+        M.ShockCooling3()
+    m = M.ShockCooling()
+    m.input_names.append('\\sigma')
+    assert M.ShockCooling().nparams == 5  # instance-level list: no cross-instance leak
+    assert (M.k_B, M.c1, M.c2, M.c3, M.c4) == tuple(golden('primitives')['const/values'][[0, 3, 4, 1, 2]])
+    assert M.ShockCooling.t_max([1., 1., 1., 2., 0.5]) == pytest.approx(7.4 * 2 ** 0.55 + 0.5)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/lcf.h declares is exported by the built library with the binding's prototype."""
+    header = open(os.path.join(ROOT, 'include', 'lcf.h')).read()
+    declared = set(re.findall(r'\b(lcf_[a-z_0-9]+)\s*\(', header))
+    bound = {name for name, _, _ in E.SIGNATURES}
+    assert declared == bound, declared ^ bound
+    lib = E.load_library()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.lcf_abi_version() == E.LCF_ABI_VERSION
+    assert ctypes.sizeof(E.LcfPrior) == 40
+
+
+def test_engine_fails_loudly_without_gpu():
+    lib = E.load_library()
+    if lib.lcf_device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(E.LcfError, match='LCF_ERR_NO_DEVICE'):
+        M.blackbody_to_filters(['g'], np.array([10.]), np.array([1.]))
+    lc = {'MJD': [1., 2.], 'filter': ['g', 'r'], 'lum': [1e20, 1e20], 'dlum': [1e18, 1e18]}
+    with pytest.raises(E.LcfError, match='no CPU fallback'):
+        M.ShockCooling().log_likelihood(lc, np.array([1., 1., 1., 1., 0.]))
+
+
+def test_engine_argument_validation_precedes_device_use():
+    lib = E.load_library()
+    pr = E.LcfProblem()
+    h = ctypes.c_void_p()
+    assert lib.lcf_engine_create(ctypes.byref(pr), 0, ctypes.byref(h)) == 1  # abi_version 0
+    assert b'abi_version' in lib.lcf_last_error()
+    assert lib.lcf_engine_create(None, 0, ctypes.byref(h)) == 1
+    with pytest.raises(ValueError):
+        E.Engine(1, 5, [], [1., 2.], [1.], [1., 1.], [0, 0], [0, 1], [1.], [1.])
+    with pytest.raises(Exception, match='sigma_type'):
+        M.ShockCooling().make_engine([1.], ['g'], [1.], [1.], sigma_type='bogus')
+    assert lib.lcf_log_likelihood(None, 1, None, None) == 1
+    assert lib.lcf_sampler_create(None, 4, 0, 2.0, ctypes.byref(h)) == 1
+
+
+def test_rng_and_shards():
+    assert [int(x) for x in rng.philox4x32(0, 0, 0, 0, 0, 0)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    perm = rng.split_permutations(99, 10, 5, 64)
+    assert perm.shape == (5, 64) and all(sorted(r) == list(range(64)) for r in perm)
+    assert not np.array_equal(perm[0], perm[1])
+    assert np.array_equal(perm[2], rng.split_permutations(99, 12, 1, 64)[0])  # keyed by absolute step
+    for n, w in ((512, 8), (10, 4), (3, 8), (7, 2)):
+        spans = [S.shard_bounds(n, w, r) for r in range(w)]
+        covered = [i for lo, hi, _ in spans for i in range(lo, hi)]
+        assert covered == list(range(n)) and all(hi - lo <= width for lo, hi, width in spans)
+
+
+def test_lightcurve_mcmc_argument_checks():
+    from lightcurve_fitting_amd.fitting import lightcurve_mcmc
+    lc = {'MJD': [1., 2.], 'filter': ['g', 'r'], 'lum': [1e20, 1e20], 'dlum': [1e18, 1e18]}
+    m = M.ShockCooling2()
+    with pytest.raises(Exception, match='p_up must have length 4'):
+        lightcurve_mcmc(lc, m, p_lo=[1, 1, 1, 0], p_up=[2, 2, 2])
+    with pytest.raises(Exception, match='priors must have length 4'):
+        lightcurve_mcmc(lc, m, priors=[M.UniformPrior(0, 1)], p_lo=[1, 1, 1, 0], p_up=[2, 2, 2, 1])
+    with pytest.raises(Exception, match='outside prior'):
+        lightcurve_mcmc(lc, m, priors=[M.UniformPrior(0, 1.5)] * 4, p_lo=[1, 1, 1, 0], p_up=[2, 2, 2, 1])
+    with pytest.raises(Exception, match='deprecated'):
+        lightcurve_mcmc(lc, m, p_lo=[1, 1, 1, 0], p_up=[2, 2, 2, 1], model_kwargs={})
