@@ -119,6 +119,8 @@ def blackbody_to_filters_batch(bands, T, R, z=0., cutoff_freq=np.inf):
     is integrated for all of its points (and all walkers) at once."""
     T = np.asarray(T, dtype=np.float64)
     R = np.asarray(R, dtype=np.float64)
+    if T.ndim == 0:  # a single data point: np.squeeze upstream collapsed the axis (models.py:267-268)
+        T, R = T.reshape(1), R.reshape(1)
     out = np.empty(T.shape, dtype=np.float64)
     names = np.array([b.name for b in bands])
     for nm in dict.fromkeys(names.tolist()):
