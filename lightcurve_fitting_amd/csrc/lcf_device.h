@@ -56,6 +56,8 @@ struct DevProblem {
     const int* pt_orig;  // index in the caller's order
     const int* chunk_lo; // per chunk: first table sample needed
     const int* chunk_n;  // per chunk: number of table samples needed
+    const int* chunk_order;  // chunks by descending cost (longest-processing-time-first dispatch)
+    const double* exp2tab;   // 2^(j/64), j = 0..63
     const double2* tab;  // (a_k, W_k)
     const int* f_kpar;
     const int* f_spar;
@@ -85,55 +87,76 @@ __device__ inline double band_sum_ref(TabPtr tab, int cnt, double invT) {
     return acc;
 }
 
-// exp(-x) for x >= 0 by a 64-entry table 2^(j/64) (registers of the polynomial stay wave-private; the table is in
-// LDS) and a degree-5 polynomial on |r| <= ln2/128.  Relative error < 2e-16 + |x| * 1.2e-16.
-// Underflows gradually and returns exactly 0 for x >= 746.5 (also for NaN).
+// Variant 1 (default).  u = exp(-x) through t' = -x * 64/ln2 = n + r (n integer, |r| <= 1/2):
+//   exp(-x) = 2^(n >> 6) * 2^((n & 63)/64) * exp(r ln2/64)
+// with a 64-entry table of 2^(j/64) in LDS and a degree-5 polynomial (truncation 3.5e-17).  Relative error
+// ~2e-16 + |x| * 2.2e-16 (the second term is the conditioning of exp: x itself carries one rounding).
+// FAST path (all samples of the wave have x < 700): the binary exponent is added with one integer add.
+// SAFE path: clamps x so that the result underflows gradually and is exactly 0 from x = 746.5 on (like the
+// reference's 1/inf), through v_ldexp_f64.  Both paths give bitwise identical values where the FAST path is valid,
+// so the result does not depend on which lanes share a wave.
 struct ExpTab {
-    const double* t;  // LDS: t[j] = 2^(-j/64), j = 0..63
+    const double* t;  // LDS: t[j] = 2^(j/64), j = 0..63
 };
 
-__device__ inline double exp_neg(double x, const ExpTab et) {
-    // n = round(x * 64/ln2); x = n*ln2/64 + r
-    const double kInv = 92.33248261689366;        // 64 / ln 2
-    const double kHi = 0x1.62e42fef80000p-7;       // ln2/64 truncated to 35 bits: n*kHi is exact for n < 2^18
-    const double kLo = 0x1.1cf79abc9e3b4p-42;      // ln2/64 - kHi
-    x = fmin(x, 746.5);  // 2^-1076 * (p tj <= 1.01) rounds to exactly 0, like the reference's 1/inf
-    const double nf = rint(x * kInv);
-    double r = fma(nf, -kHi, x);
-    r = fma(nf, -kLo, r);  // r in [-ln2/128, ln2/128], we need exp(-r)
+constexpr double kInv64 = 92.33248261689366;  // 64 / ln 2
+constexpr double kQ1 = 0.010830424696249145, kQ2 = 5.864904955056169e-05, kQ3 = 2.1173137155464774e-07, kQ4 = 5.732851688640402e-10, kQ5 = 1.2417843701716923e-12;
+
+template <bool SAFE>
+__device__ inline double exp_scaled(double tp, const ExpTab et) {
+    if (SAFE) tp = fmax(tp, -746.5 * kInv64);
+    const double nf = rint(tp);
+    const double r = tp - nf;  // exact
     const int n = (int)nf;
     const double tj = et.t[n & 63];
-    // exp(-r) = 1 - r + r^2/2 - r^3/6 + r^4/24 - r^5/120
-    double p = fma(r, -1. / 120., 1. / 24.);
-    p = fma(p, r, -1. / 6.);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, -1.);
-    p = fma(p, r, 1.);  // = exp(-r) up to r^6/720 < 3.4e-17
-    return ldexp(p * tj, -(n >> 6));
+    double p = fma(r, kQ5, kQ4);
+    p = fma(p, r, kQ3);
+    p = fma(p, r, kQ2);
+    p = fma(p, r, kQ1);
+    p = fma(p, r, 1.0);
+    const double v = p * tj;  // in [0.99, 2.01)
+    const int e = n >> 6;
+    if (SAFE) return ldexp(v, e);
+    return __hiloint2double(__double2hiint(v) + (int)((unsigned)e << 20), __double2loint(v));
 }
 
-// Variant 1: u = exp(-x); W/(e^x - 1) = W u / (1 - u).  Four samples share one division:
-//   n1/d1 + n2/d2 = (n1 d2 + n2 d1) / (d1 d2)   with d in (0, 1], so nothing overflows; products of four d's
-//   stay far above the subnormal range unless all four x < 1e-77, which the guard below excludes.
-template <class TabPtr>
-__device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const ExpTab et) {
+// n / d for d in [1e-250, 1]: reciprocal seed + two Newton steps + one residual correction (<= 1 ulp).
+__device__ inline double div_pos(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
+// W/(e^x - 1) = W u/(1 - u) with u = e^-x.  Four samples share one division:
+//   n1/d1 + n2/d2 = (n1 d2 + n2 d1)/(d1 d2),   every d in (0, 1] so nothing overflows.
+// Tables are padded to a multiple of four samples with zero weights (contribute exactly 0).
+template <bool SAFE, class TabPtr>
+__device__ inline double band_sum_quads(TabPtr tab, int cnt, double sneg, const ExpTab et) {
     double acc = 0.;
-    int k = 0;
-    for (; k + 4 <= cnt; k += 4) {
+    for (int k = 0; k < cnt; k += 4) {
         const double2 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
-        const double u0 = exp_neg(s0.x * invT, et), u1 = exp_neg(s1.x * invT, et);
-        const double u2 = exp_neg(s2.x * invT, et), u3 = exp_neg(s3.x * invT, et);
+        const double u0 = exp_scaled<SAFE>(s0.x * sneg, et), u1 = exp_scaled<SAFE>(s1.x * sneg, et);
+        const double u2 = exp_scaled<SAFE>(s2.x * sneg, et), u3 = exp_scaled<SAFE>(s3.x * sneg, et);
         const double d0 = 1. - u0, d1 = 1. - u1, d2 = 1. - u2, d3 = 1. - u3;
         const double n01 = fma(s0.y * u0, d1, s1.y * u1 * d0), d01 = d0 * d1;
         const double n23 = fma(s2.y * u2, d3, s3.y * u3 * d2), d23 = d2 * d3;
-        acc += fma(n01, d23, n23 * d01) / (d01 * d23);
-    }
-    for (; k < cnt; ++k) {
-        const double2 s = tab[k];
-        const double u = exp_neg(s.x * invT, et);
-        acc += s.y * u / (1. - u);
+        acc += div_pos(fma(n01, d23, n23 * d01), d01 * d23);
     }
     return acc;
+}
+
+template <class TabPtr>
+__device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const ExpTab et) {
+    if (cnt <= 0) return 0.;
+    const double amax = fmax(tab[0].x, tab[cnt - 1].x);  // tables are monotonic in a_k
+    const double sneg = -invT * kInv64;
+    const bool needs_safe = !(amax * invT < 700.);
+    if (__builtin_amdgcn_ballot_w64(needs_safe) == 0) return band_sum_quads<false>(tab, cnt, sneg, et);
+    return band_sum_quads<true>(tab, cnt, sneg, et);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

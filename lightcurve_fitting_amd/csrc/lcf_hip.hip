@@ -85,7 +85,7 @@ __device__ inline PointOut point_model(const DevProblem& pb, const double* __res
 
 // MODE 0: chi^2 partial sums -> part[w][chunk];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
 template <int VARIANT, int MODE, bool LDS_TAB>
-__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, const double* __restrict__ P,
+__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
                                                    const double* __restrict__ coef,
                                                    const double* __restrict__ lprior, double* __restrict__ out0,
                                                    double* __restrict__ out1) {
@@ -94,13 +94,14 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
     double* red = exptab + 64;                                            // 4 doubles
     double2* ltab = reinterpret_cast<double2*>(smem + (64 + 8) * sizeof(double));
 
-    const int chunk = blockIdx.x % pb.n_chunks;
-    const int w = w_lo + blockIdx.x / pb.n_chunks;
+    // heaviest chunks (widest band tables) are dispatched first so that the grid drains evenly
+    const int chunk = pb.chunk_order[blockIdx.x / n_w];
+    const int w = w_lo + blockIdx.x % n_w;
     const int tid = threadIdx.x;
 
     if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
 
-    if (VARIANT == 1 && tid < 64) exptab[tid] = exp2(-(double)tid * (1. / 64.));
+    if (VARIANT == 1 && tid < 64) exptab[tid] = pb.exp2tab[tid];
     const int tlo = pb.chunk_lo[chunk];
     if (LDS_TAB) {
         const int tn = pb.chunk_n[chunk];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
                                                          const double* __restrict__ T, const double* __restrict__ R,
                                                          double* __restrict__ out) {
     __shared__ double exptab[64];
-    if (threadIdx.x < 64) exptab[threadIdx.x] = exp2(-(double)threadIdx.x * (1. / 64.));
+    if (threadIdx.x < 64) exptab[threadIdx.x] = pb.exp2tab[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -402,14 +403,14 @@ void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const
     const size_t lds = e->lds_bytes;
     if (pb.variant == 0) {
         if (pb.tab_in_lds)
-            hipLaunchKernelGGL((k_points<0, MODE, true>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+            hipLaunchKernelGGL((k_points<0, MODE, true>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
         else
-            hipLaunchKernelGGL((k_points<0, MODE, false>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+            hipLaunchKernelGGL((k_points<0, MODE, false>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
     } else {
         if (pb.tab_in_lds)
-            hipLaunchKernelGGL((k_points<1, MODE, true>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+            hipLaunchKernelGGL((k_points<1, MODE, true>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
         else
-            hipLaunchKernelGGL((k_points<1, MODE, false>), grid, block, lds, st, pb, w_lo, dP, coef, lprior, out0, out1);
+            hipLaunchKernelGGL((k_points<1, MODE, false>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
     }
 }
 
@@ -516,6 +517,22 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<int> hoff(N), hcnt(N), hfilt(N), horig(N);
     double lognorm = 0.;
     int64_t samples = 0;
+    // device tables: every filter padded to a multiple of four samples with zero weights (exactly 0 contribution)
+    std::vector<int> poff(NF + 1, 0);
+    std::vector<double2> htab;
+    for (int f = 0; f < NF; ++f) {
+        const int k0 = pr->tab_off[f], k1 = pr->tab_off[f + 1];
+        for (int k = k0; k < k1; ++k) {
+            if (!(pr->tab_a[k] > 0.) || !std::isfinite(pr->tab_a[k]) || !std::isfinite(pr->tab_w[k])) {
+                delete e;
+                return fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0 and finite W_k");
+            }
+            htab.push_back(make_double2(pr->tab_a[k], pr->tab_w[k]));
+        }
+        const double apad = k1 > k0 ? pr->tab_a[k1 - 1] : 1.;
+        while ((htab.size() - poff[f]) % 4) htab.push_back(make_double2(apad, 0.));
+        poff[f + 1] = (int)htab.size();
+    }
     for (int i = 0; i < N; ++i) {
         const int o = order[i], f = pr->filt_idx[o];
         ht[i] = pr->t[o];
@@ -523,9 +540,9 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         hdy[i] = pr->dy[o];
         hfilt[i] = f;
         horig[i] = o;
-        hoff[i] = pr->tab_off[f];
-        hcnt[i] = pr->tab_off[f + 1] - pr->tab_off[f];
-        samples += hcnt[i];
+        hoff[i] = poff[f];
+        hcnt[i] = poff[f + 1] - poff[f];
+        samples += pr->tab_off[f + 1] - pr->tab_off[f];
     }
     for (int i = 0; i < N; ++i) lognorm += std::log(2. * M_PI * pr->dy[i] * pr->dy[i]);  // caller order, like np.sum
     std::vector<double> sorted_dy(pr->dy, pr->dy + N);
@@ -549,10 +566,15 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         cn[c] = hi - lo;
         max_cn = std::max(max_cn, cn[c]);
     }
-    const int ntab = pr->tab_off[NF];
-    std::vector<double2> htab(ntab);
-    for (int k = 0; k < ntab; ++k) htab[k] = make_double2(pr->tab_a[k], pr->tab_w[k]);
-    std::vector<int> htaboff(pr->tab_off, pr->tab_off + NF + 1);
+    std::vector<int> htaboff(poff);
+    if (htab.empty()) htab.push_back(make_double2(1., 0.));
+    std::vector<int> corder(n_chunks);
+    std::iota(corder.begin(), corder.end(), 0);
+    std::vector<long long> ccost(n_chunks, 0);
+    for (int i = 0; i < N; ++i) ccost[i / kBlock] += hcnt[i] + 12;  // samples + per-point overhead
+    std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return ccost[a] > ccost[b]; });
+    std::vector<double> hexp(64);
+    for (int j = 0; j < 64; ++j) hexp[j] = std::exp2(j / 64.);
 
     DevProblem& dp = e->dp;
     dp.model = pr->model;
@@ -580,6 +602,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
     UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hoff, doff); UP(hcnt, dcnt); UP(hfilt, dfilt); UP(horig, dorig);
     UP(clo, dclo); UP(cn, dcn); UP(htab, dtab); UP(htaboff, e->d_tab_off);
+    int* dcord;
+    double* dexp;
+    UP(corder, dcord); UP(hexp, dexp);
+    dp.chunk_order = dcord;
+    dp.exp2tab = dexp;
     if (companion) {
         std::vector<int> hk(pr->filt_kasen_par, pr->filt_kasen_par + NF), hs(pr->filt_sifto_par, pr->filt_sifto_par + NF),
             hd(pr->filt_dt_par, pr->filt_dt_par + NF);
