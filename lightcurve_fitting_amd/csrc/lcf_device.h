@@ -12,7 +12,7 @@ namespace lcf {
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kNCoef = 8;        // derived per-walker coefficients
 constexpr int kMaxDim = 16;      // max parameters per walker
-constexpr int kLdsTabMax = 4000; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
+constexpr int kLdsTabMax = 3900; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
 
 constexpr double kKB = 0.08617333262145178;   // eV / kK                 models.py:10
 constexpr double kC3 = 5.38477047522316e-19;  //                          models.py:11
@@ -57,7 +57,7 @@ struct DevProblem {
     const int* chunk_lo; // per chunk: first table sample needed
     const int* chunk_n;  // per chunk: number of table samples needed
     const int* chunk_order;  // chunks by descending cost (longest-processing-time-first dispatch)
-    const double* exp2tab;   // 2^(j/64), j = 0..63
+    const double* exp2tab;   // 2^(j/256), j = 0..255
     const double2* tab;  // (a_k, W_k)
     const int* f_kpar;
     const int* f_spar;
@@ -87,40 +87,43 @@ __device__ inline double band_sum_ref(TabPtr tab, int cnt, double invT) {
     return acc;
 }
 
-// Variant 1 (default).  u = exp(-x) through t' = -x * 64/ln2 = n + r (n integer, |r| <= 1/2):
-//   exp(-x) = 2^(n >> 6) * 2^((n & 63)/64) * exp(r ln2/64)
-// with a 64-entry table of 2^(j/64) in LDS and a degree-5 polynomial (truncation 3.5e-17).  Relative error
-// ~2e-16 + |x| * 2.2e-16 (the second term is the conditioning of exp: x itself carries one rounding).
-// FAST path (all samples of the wave have x < 700): the binary exponent is added with one integer add.
-// SAFE path: clamps x so that the result underflows gradually and is exactly 0 from x = 746.5 on (like the
-// reference's 1/inf), through v_ldexp_f64.  Both paths give bitwise identical values where the FAST path is valid,
-// so the result does not depend on which lanes share a wave.
+// Variant 1 (default).  exp(+-x) through t = +-x * 256/ln2 = n + r (n integer, |r| <= 1/2):
+//   exp(+-x) = 2^(n >> 8) * 2^((n & 255)/256) * exp(r ln2/256)
+// with a 256-entry table of 2^(j/256) in LDS (2 KiB) and a degree-4 polynomial (truncation 3.8e-17).  Relative
+// error ~2e-16 + |x| * 2.2e-16 (the second term is the conditioning of exp: x itself carries one rounding).
+// MAIN path (every sample of the wave has x < 170): E = e^x, term = W/(E - 1), the binary exponent is added with
+//   one integer add; the four denominators of a quad multiply to < e^680, no overflow.  E - 1 has the same
+//   cancellation behaviour as the reference's own exp(x) - 1.
+// SAFE path (some x >= 170, i.e. T below ~0.3 kK): u = e^-x, term = W u/(1 - u), x clamped so that the result
+//   underflows gradually and is exactly 0 from x = 746.5 on (like the reference's 1/inf), through v_ldexp_f64.
+// The path is chosen per wave = 64 consecutive points of ONE walker, so a walker's result never depends on how
+// walkers are batched or sharded.
 struct ExpTab {
-    const double* t;  // LDS: t[j] = 2^(j/64), j = 0..63
+    const double* t;  // LDS: t[j] = 2^(j/256), j = 0..255
 };
 
-constexpr double kInv64 = 92.33248261689366;  // 64 / ln 2
-constexpr double kQ1 = 0.010830424696249145, kQ2 = 5.864904955056169e-05, kQ3 = 2.1173137155464774e-07, kQ4 = 5.732851688640402e-10, kQ5 = 1.2417843701716923e-12;
+constexpr int kExpTabSize = 256;
+constexpr double kInvLn2N = 369.3299304675746;  // 256 / ln 2
+constexpr double kQ1 = 0.0027076061740622863, kQ2 = 3.665565596910106e-06, kQ3 = 3.308302680541371e-09, kQ4 = 2.239395190875157e-12;
 
 template <bool SAFE>
 __device__ inline double exp_scaled(double tp, const ExpTab et) {
-    if (SAFE) tp = fmax(tp, -746.5 * kInv64);
+    if (SAFE) tp = fmax(tp, -746.5 * kInvLn2N);
     const double nf = rint(tp);
     const double r = tp - nf;  // exact
     const int n = (int)nf;
-    const double tj = et.t[n & 63];
-    double p = fma(r, kQ5, kQ4);
-    p = fma(p, r, kQ3);
+    const double tj = et.t[n & (kExpTabSize - 1)];
+    double p = fma(r, kQ4, kQ3);
     p = fma(p, r, kQ2);
     p = fma(p, r, kQ1);
     p = fma(p, r, 1.0);
     const double v = p * tj;  // in [0.99, 2.01)
-    const int e = n >> 6;
+    const int e = n >> 8;
     if (SAFE) return ldexp(v, e);
     return __hiloint2double(__double2hiint(v) + (int)((unsigned)e << 20), __double2loint(v));
 }
 
-// n / d for d in [1e-250, 1]: reciprocal seed + two Newton steps + one residual correction (<= 1 ulp).
+// n / d for positive normal d: reciprocal seed + two Newton steps (error ~1 ulp).
 __device__ inline double div_pos(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
     double e = fma(-d, r, 1.0);
@@ -131,17 +134,30 @@ __device__ inline double div_pos(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
-// W/(e^x - 1) = W u/(1 - u) with u = e^-x.  Four samples share one division:
-//   n1/d1 + n2/d2 = (n1 d2 + n2 d1)/(d1 d2),   every d in (0, 1] so nothing overflows.
+// Four samples share one division:  n1/d1 + n2/d2 = (n1 d2 + n2 d1)/(d1 d2).
 // Tables are padded to a multiple of four samples with zero weights (contribute exactly 0).
-template <bool SAFE, class TabPtr>
-__device__ inline double band_sum_quads(TabPtr tab, int cnt, double sneg, const ExpTab et) {
+template <class TabPtr>
+__device__ inline double band_sum_main(TabPtr tab, int cnt, double spos, const ExpTab et) {
     double acc = 0.;
     for (int k = 0; k < cnt; k += 4) {
         const double2 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
-        const double u0 = exp_scaled<SAFE>(s0.x * sneg, et), u1 = exp_scaled<SAFE>(s1.x * sneg, et);
-        const double u2 = exp_scaled<SAFE>(s2.x * sneg, et), u3 = exp_scaled<SAFE>(s3.x * sneg, et);
-        const double d0 = 1. - u0, d1 = 1. - u1, d2 = 1. - u2, d3 = 1. - u3;
+        const double d0 = exp_scaled<false>(s0.x * spos, et) - 1., d1 = exp_scaled<false>(s1.x * spos, et) - 1.;
+        const double d2 = exp_scaled<false>(s2.x * spos, et) - 1., d3 = exp_scaled<false>(s3.x * spos, et) - 1.;
+        const double n01 = fma(s0.y, d1, s1.y * d0), d01 = d0 * d1;
+        const double n23 = fma(s2.y, d3, s3.y * d2), d23 = d2 * d3;
+        acc += div_pos(fma(n01, d23, n23 * d01), d01 * d23);
+    }
+    return acc;
+}
+
+template <class TabPtr>
+__device__ inline double band_sum_safe(TabPtr tab, int cnt, double sneg, const ExpTab et) {
+    double acc = 0.;
+    for (int k = 0; k < cnt; k += 4) {
+        const double2 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
+        const double u0 = exp_scaled<true>(s0.x * sneg, et), u1 = exp_scaled<true>(s1.x * sneg, et);
+        const double u2 = exp_scaled<true>(s2.x * sneg, et), u3 = exp_scaled<true>(s3.x * sneg, et);
+        const double d0 = 1. - u0, d1 = 1. - u1, d2 = 1. - u2, d3 = 1. - u3;  // all in (0, 1]
         const double n01 = fma(s0.y * u0, d1, s1.y * u1 * d0), d01 = d0 * d1;
         const double n23 = fma(s2.y * u2, d3, s3.y * u3 * d2), d23 = d2 * d3;
         acc += div_pos(fma(n01, d23, n23 * d01), d01 * d23);
@@ -153,10 +169,10 @@ template <class TabPtr>
 __device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const ExpTab et) {
     if (cnt <= 0) return 0.;
     const double amax = fmax(tab[0].x, tab[cnt - 1].x);  // tables are monotonic in a_k
-    const double sneg = -invT * kInv64;
-    const bool needs_safe = !(amax * invT < 700.);
-    if (__builtin_amdgcn_ballot_w64(needs_safe) == 0) return band_sum_quads<false>(tab, cnt, sneg, et);
-    return band_sum_quads<true>(tab, cnt, sneg, et);
+    const double spos = invT * kInvLn2N;
+    const bool needs_safe = !(amax * invT < 170.);
+    if (__builtin_amdgcn_ballot_w64(needs_safe) == 0) return band_sum_main(tab, cnt, spos, et);
+    return band_sum_safe(tab, cnt, -spos, et);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
                                                    const double* __restrict__ lprior, double* __restrict__ out0,
                                                    double* __restrict__ out1) {
     extern __shared__ __align__(16) unsigned char smem[];
-    double* exptab = reinterpret_cast<double*>(smem);                     // 64 doubles
-    double* red = exptab + 64;                                            // 4 doubles
-    double2* ltab = reinterpret_cast<double2*>(smem + (64 + 8) * sizeof(double));
+    double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
+    double* red = exptab + kExpTabSize;                                   // 4 doubles
+    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
 
     // heaviest chunks (widest band tables) are dispatched first so that the grid drains evenly
     const int chunk = pb.chunk_order[blockIdx.x / n_w];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
 
     if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
 
-    if (VARIANT == 1 && tid < 64) exptab[tid] = pb.exp2tab[tid];
+    if (VARIANT == 1 && tid < kExpTabSize) exptab[tid] = pb.exp2tab[tid];
     const int tlo = pb.chunk_lo[chunk];
     if (LDS_TAB) {
         const int tn = pb.chunk_n[chunk];
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
                                                          const int* __restrict__ tab_off,
                                                          const double* __restrict__ T, const double* __restrict__ R,
                                                          double* __restrict__ out) {
-    __shared__ double exptab[64];
-    if (threadIdx.x < 64) exptab[threadIdx.x] = pb.exp2tab[threadIdx.x];
+    __shared__ double exptab[kExpTabSize];
+    if (threadIdx.x < kExpTabSize) exptab[threadIdx.x] = pb.exp2tab[threadIdx.x];
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -573,8 +573,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<long long> ccost(n_chunks, 0);
     for (int i = 0; i < N; ++i) ccost[i / kBlock] += hcnt[i] + 12;  // samples + per-point overhead
     std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return ccost[a] > ccost[b]; });
-    std::vector<double> hexp(64);
-    for (int j = 0; j < 64; ++j) hexp[j] = std::exp2(j / 64.);
+    std::vector<double> hexp(kExpTabSize);
+    for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
 
     DevProblem& dp = e->dp;
     dp.model = pr->model;
@@ -593,7 +593,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
-    e->lds_bytes = (64 + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)std::max(max_cn, 1) * sizeof(double2) : 0);
+    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)std::max(max_cn, 1) * sizeof(double2) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
     int *doff, *dcnt, *dfilt, *dorig, *dclo, *dcn, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
