@@ -43,6 +43,7 @@ struct DevProblem {
     int model, n_points, n_chunks, n_filters;
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
+    int n_epochs, use_therm, pad0, pad1;
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double sigma_unit_abs;  // median(dy)
@@ -54,6 +55,8 @@ struct DevProblem {
     const int* pt_cnt;   // number of table samples
     const int* pt_filt;  // filter index
     const int* pt_orig;  // index in the caller's order
+    const int* pt_epoch; // index into epoch_t (distinct observation times)
+    const double* epoch_t; // [n_epochs]
     const int* chunk_lo; // per chunk: first table sample needed
     const int* chunk_n;  // per chunk: number of table samples needed
     const int* chunk_order;  // chunks by descending cost (longest-processing-time-first dispatch)
@@ -193,10 +196,19 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
         case kShockCooling: {  // models.py:260-267
             const double A = k[0], a = k[1], alpha = k[2], eps1 = k[3], eps2 = k[4], L0 = k[5], T0 = k[6], ratio = k[7];
             const double v = p[0], M = p[1], f = p[2], R = p[3];
+            c[0] = p[4];
+            if (v > 0. && M > 0. && f > 0. && R > 0. && v < 1e100 && M < 1e100 && f < 1e100 && R < 1e100) {
+                // all bases positive: every power() is a plain power; share the four logarithms
+                const double lv = log(v), lM = log(M), lf = log(f), lR = log(R);
+                c[1] = (T0 * ratio / kKB) * exp(eps1 * (2. * lv - lf) + 0.25 * lR);
+                c[2] = (L0 * A) * exp(-eps2 * (lv - lf) + 2. * lv + lR);
+                c[3] = a > 0. ? alpha * (log(a / 19.5) - 0.5 * (lM - lv)) : qnan();
+                c[4] = 0.;
+                break;
+            }
             const double Lc = L0 * pw(v / f, -eps2) * v * v * R;  // L_RW = Lc * |t|^(-2 eps2)
             const double t_tr = 19.5 * sqrt(M / v);
             const double g = a / t_tr;
-            c[0] = p[4];
             c[1] = T0 * pw(v * v / f, eps1) * pow(R, 0.25) * ratio / kKB;
             c[2] = Lc * A;
             c[3] = g > 0. ? alpha * log(g) : qnan();
@@ -215,10 +227,18 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
         case kShockCooling4: {  // models.py:584-587 (quirks kept: no kappa in t_br, right-associative ** chain)
             const double v = p[0], M = p[1], f = p[2], R = p[3];
             c[0] = p[4];
+            c[4] = k[6] * sqrt(M / v);
+            if (v > 0. && f > 0. && R > 0. && v < 1e100 && f < 1e100 && R < 1e100) {
+                const double lv = log(v), lf = log(f), lR = log(R);
+                const double ex = exp(-0.5447271754416722 * exp(0.03 * lf));  // 0.58 ** (f ** 0.03)
+                c[1] = (k[4] / kKB) * exp(-0.32 * lR + ex * lv);
+                c[2] = k[3] * exp(0.78 * lR + 2.11 * lv + 0.11 * lf);
+                c[3] = k[5] * exp(1.26 * lR - 1.13 * lv - 0.13 * lf);
+                break;
+            }
             c[1] = k[4] * pow(R, -0.32) * pow(v, pow(0.58, pow(f, 0.03))) / kKB;
             c[2] = k[3] * pow(R, 0.78) * pow(v, 2.11) * pow(f, 0.11);
             c[3] = k[5] * pow(R, 1.26) * pow(v, -1.13) * pow(f, -0.13);
-            c[4] = k[6] * sqrt(M / v);
             break;
         }
         case kCompanion:
@@ -227,9 +247,15 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             const double a13 = p[1];
             const double Mv = pb.model == kCompanion3 ? 1. : p[2];
             c[0] = p[0];
-            c[1] = 25. * pw(pow(a13, 36.) * Mv, 1. / 144.);
-            const double rc = 2.7 * pw(Mv, 1. / 9.);
-            c[2] = rc * rc;
+            if (a13 > 0. && Mv > 0. && a13 < 1e8 && a13 > 1e-8 && Mv < 1e100) {
+                const double la = log(a13), lm = log(Mv);
+                c[1] = 25. * exp((36. * la + lm) * (1. / 144.));
+                c[2] = 7.29 * exp(lm * (2. / 9.));
+            } else {
+                c[1] = 25. * pw(pow(a13, 36.) * Mv, 1. / 144.);
+                const double rc = 2.7 * pw(Mv, 1. / 9.);
+                c[2] = rc * rc;
+            }
             c[3] = p[3];
             c[4] = p[4];
             if (pb.model == kCompanion3) {

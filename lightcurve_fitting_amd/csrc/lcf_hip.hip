@@ -56,9 +56,10 @@ struct PointOut {
 template <int VARIANT, class TabPtr>
 __device__ inline PointOut point_model(const DevProblem& pb, const double* __restrict__ c,
                                        const double* __restrict__ p, double t_in, int filt, TabPtr tab, int cnt,
-                                       const ExpTab et) {
+                                       const ExpTab et, double T, double pref) {
     PointOut o;
-    thermal_state(pb, c, t_in, o.T, o.pref);
+    o.T = T;
+    o.pref = pref;
     double S = 0.;
     if (o.T > 0.) {
         const double invT = 1. / o.T;
@@ -83,11 +84,28 @@ __device__ inline PointOut point_model(const DevProblem& pb, const double* __res
     return o;
 }
 
+// Thermal state (T, R_bb^2) of every (walker, distinct observation time): light curves observed in several filters at
+// the same epochs share it, so the logarithm and exponentials of the model are paid once per epoch instead of once
+// per point.  Used when the light curve has at least two points per distinct time on average.
+__global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_lo, int n_w,
+                                                    const double* __restrict__ coef,
+                                                    const double* __restrict__ lprior, int skip_excluded,
+                                                    double2* __restrict__ therm) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_w * pb.n_epochs) return;
+    const int w = w_lo + idx / pb.n_epochs, ep = idx % pb.n_epochs;
+    if (skip_excluded && lprior[w] == -INFINITY) return;
+    double T, pref;
+    thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, pref);
+    therm[(size_t)w * pb.n_epochs + ep] = make_double2(T, pref);
+}
+
 // MODE 0: chi^2 partial sums -> part[w][chunk];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
-template <int VARIANT, int MODE, bool LDS_TAB>
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
 __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
                                                    const double* __restrict__ coef,
-                                                   const double* __restrict__ lprior, double* __restrict__ out0,
+                                                   const double* __restrict__ lprior,
+                                                   const double2* __restrict__ therm, double* __restrict__ out0,
                                                    double* __restrict__ out1) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
@@ -120,10 +138,18 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
         const int filt = pb.pt_filt[i];
         const int off = pb.pt_off[i], cnt = pb.pt_cnt[i];
         PointOut o;
-        if (LDS_TAB) {
-            o = point_model<VARIANT>(pb, c, p, t_in, filt, (const double2*)(ltab + (off - tlo)), cnt, et);
+        double T, pref;
+        if (THERM) {
+            const double2 tp = therm[(size_t)w * pb.n_epochs + pb.pt_epoch[i]];
+            T = tp.x;
+            pref = tp.y;
         } else {
-            o = point_model<VARIANT>(pb, c, p, t_in, filt, pb.tab + off, cnt, et);
+            thermal_state(pb, c, t_in, T, pref);
+        }
+        if (LDS_TAB) {
+            o = point_model<VARIANT>(pb, c, p, t_in, filt, (const double2*)(ltab + (off - tlo)), cnt, et, T, pref);
+        } else {
+            o = point_model<VARIANT>(pb, c, p, t_in, filt, pb.tab + off, cnt, et, T, pref);
         }
         if (MODE == 0) {  // models.py:121-135
             const double dy = pb.dy[i];
@@ -247,11 +273,10 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
         perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
 }
 
-// Stretch-move proposal for the active half + the proposal's derived coefficients and log-prior (fused prepare).
-__global__ void k_propose(const DevProblem pb, const DevSampler sm, const int* __restrict__ perm, long long step,
-                          long long chain_row, int half, double* __restrict__ coef, double* __restrict__ lprior) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sm.n_half) return;
+// Stretch-move proposal of active walker slot i + the proposal's derived coefficients and log-prior.
+__device__ inline void propose_one(const DevProblem& pb, const DevSampler& sm, const int* __restrict__ perm,
+                                   long long step, int half, int i, double* __restrict__ coef,
+                                   double* __restrict__ lprior) {
     const int n_other = sm.n_walkers - sm.n_half;
     const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
     const int wid = perm ? perm[my_slot] : my_slot;
@@ -279,15 +304,21 @@ __global__ void k_propose(const DevProblem pb, const DevSampler sm, const int* _
     walker_coefficients(pb, q, c);
     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
     lprior[i] = walker_log_prior(pb, q);
-    (void)chain_row;
 }
 
-// Accept / reject for the active half, chain bookkeeping.  Reads the gathered new log-posteriors.
-__global__ void k_accept(const DevSampler sm, long long chain_row) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sm.n_half) return;
+// lnL + log-prior of proposal i from its partial sums (fixed order).
+__device__ inline double finalize_one(const DevProblem& pb, const double* __restrict__ part,
+                                      const double* __restrict__ lprior, int i) {
+    const double lp = lprior[i];
+    if (lp == -INFINITY) return -INFINITY;
+    double s = pb.use_sigma ? 0. : pb.log_norm_const;
+    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)i * pb.n_chunks + k];
+    return lp - 0.5 * s;
+}
+
+// Accept / reject of active walker slot i given its new log-posterior; chain bookkeeping.
+__device__ inline void accept_one(const DevSampler& sm, long long chain_row, int i, double nlp) {
     const int wid = sm.act[i];
-    const double nlp = sm.newlp[i];
     const double old = sm.LP[wid];
     if (nlp != nlp) atomicExch(sm.err, 1);
     const bool ok = (sm.zl[i] + nlp - old) > sm.lnu[i];
@@ -300,9 +331,39 @@ __global__ void k_accept(const DevSampler sm, long long chain_row) {
     }
     if (sm.store_chain) {
         double* row = sm.chain + ((size_t)chain_row * sm.n_walkers + wid) * sm.n_dim;
-        for (int d = 0; d < sm.n_dim; ++d) row[d] = ok ? sm.Q[(size_t)i * sm.n_dim + d] : sm.X[(size_t)wid * sm.n_dim + d];
+        for (int d = 0; d < sm.n_dim; ++d) row[d] = sm.X[(size_t)wid * sm.n_dim + d];
         sm.chain_lp[(size_t)chain_row * sm.n_walkers + wid] = lp;
     }
+}
+
+__global__ void k_propose(const DevProblem pb, const DevSampler sm, const int* __restrict__ perm, long long step,
+                          int half, double* __restrict__ coef, double* __restrict__ lprior) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < sm.n_half) propose_one(pb, sm, perm, step, half, i, coef, lprior);
+}
+
+// Reads the (gathered) new log-posteriors.
+__global__ void k_accept(const DevSampler sm, long long chain_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < sm.n_half) accept_one(sm, chain_row, i, sm.newlp[i]);
+}
+
+// Single-GPU fast path for ensembles of up to 2048 walkers: ONE workgroup finishes the previous half-step
+// (fixed-order sum of the partials, accept/reject) and, after a workgroup barrier, draws the proposals of the next
+// one.  Replaces three latency-bound launches (finalize, accept, propose) per half-step by one.
+__global__ __launch_bounds__(1024) void k_glue(const DevProblem pb, const DevSampler sm, int have_prev,
+                                               long long prev_row, int have_next, const int* __restrict__ perm,
+                                               long long step, int half, double* __restrict__ coef,
+                                               double* __restrict__ lprior, const double* __restrict__ part) {
+    const int i = threadIdx.x;
+    if (have_prev && i < sm.n_half) {
+        const double nlp = finalize_one(pb, part, lprior, i);
+        sm.newlp[i] = nlp;
+        accept_one(sm, prev_row, i, nlp);
+    }
+    __threadfence_block();
+    __syncthreads();  // every accepted position is visible before any partner is read
+    if (have_next && i < sm.n_half) propose_one(pb, sm, perm, step, half, i, coef, lprior);
 }
 
 }  // namespace
@@ -350,6 +411,7 @@ struct lcf_engine {
     // workspace for n walkers
     int64_t cap = 0;
     double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
+    double2* wtherm = nullptr;
     // scratch for evaluate-type calls
     size_t big_bytes = 0;
     double* wbig = nullptr;
@@ -366,6 +428,8 @@ struct lcf_engine {
             if (*p) hipFree(*p);
             *p = nullptr;
         }
+        if (wtherm) hipFree(wtherm);
+        wtherm = nullptr;
         cap = 0;
     }
     lcf_status reserve(int64_t n) {
@@ -378,6 +442,7 @@ struct lcf_engine {
         LCF_HIP(hipMalloc((void**)&wlprior, c * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wpart, c * dp.n_chunks * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wout, c * sizeof(double)));
+        if (dp.use_therm) LCF_HIP(hipMalloc((void**)&wtherm, c * dp.n_epochs * sizeof(double2)));
         cap = c;
         return LCF_OK;
     }
@@ -395,23 +460,35 @@ struct lcf_engine {
 
 namespace {
 
+template <int VARIANT, int MODE>
+void launch_points_v(const DevProblem& pb, dim3 grid, size_t lds, hipStream_t st, int w_lo, int n, const double* dP,
+                     const double* coef, const double* lprior, const double2* therm, double* out0, double* out1) {
+    const dim3 block(kBlock);
+#define LCF_GO(L, T) hipLaunchKernelGGL((k_points<VARIANT, MODE, L, T>), grid, block, lds, st, pb, w_lo, n, dP, coef, \
+                                        lprior, therm, out0, out1)
+    if (pb.tab_in_lds) {
+        if (pb.use_therm) LCF_GO(true, true); else LCF_GO(true, false);
+    } else {
+        if (pb.use_therm) LCF_GO(false, true); else LCF_GO(false, false);
+    }
+#undef LCF_GO
+}
+
+// Launches the per-point kernel for walkers [w_lo, w_lo + n) (absolute indices into P / coef / lprior / therm).
 template <int MODE>
 void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const double* coef, const double* lprior,
-                   double* out0, double* out1, hipStream_t st) {
+                   double2* therm, double* out0, double* out1, hipStream_t st, bool do_thermal = true) {
     const DevProblem& pb = e->dp;
-    const dim3 grid((unsigned)((size_t)n * pb.n_chunks)), block(kBlock);
-    const size_t lds = e->lds_bytes;
-    if (pb.variant == 0) {
-        if (pb.tab_in_lds)
-            hipLaunchKernelGGL((k_points<0, MODE, true>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
-        else
-            hipLaunchKernelGGL((k_points<0, MODE, false>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
-    } else {
-        if (pb.tab_in_lds)
-            hipLaunchKernelGGL((k_points<1, MODE, true>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
-        else
-            hipLaunchKernelGGL((k_points<1, MODE, false>), grid, block, lds, st, pb, w_lo, n, dP, coef, lprior, out0, out1);
+    if (pb.use_therm && do_thermal) {
+        const long long total = (long long)n * pb.n_epochs;
+        hipLaunchKernelGGL(k_thermal, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pb, w_lo, n,
+                           coef, lprior, MODE == 0 ? 1 : 0, therm);
     }
+    const dim3 grid((unsigned)((size_t)n * pb.n_chunks));
+    if (pb.variant == 0)
+        launch_points_v<0, MODE>(pb, grid, e->lds_bytes, st, w_lo, n, dP, coef, lprior, therm, out0, out1);
+    else
+        launch_points_v<1, MODE>(pb, grid, e->lds_bytes, st, w_lo, n, dP, coef, lprior, therm, out0, out1);
 }
 
 // log-likelihood / log-posterior of n walkers, device pointers, enqueue only.
@@ -420,7 +497,7 @@ lcf_status logprob_dev(lcf_engine* e, int64_t n, const double* dP, double* dout,
     const int bs = 128;
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, e->dp, (int)n, dP, e->wcoef,
                        e->wlprior, with_prior);
-    launch_points<0>(e, 0, (int)n, dP, e->wcoef, e->wlprior, e->wpart, nullptr, st);
+    launch_points<0>(e, 0, (int)n, dP, e->wcoef, e->wlprior, e->wtherm, e->wpart, nullptr, st);
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st, e->dp, (int)n, e->wpart,
                        e->wlprior, dout);
     LCF_HIP(hipGetLastError());
@@ -551,6 +628,14 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         std::sort(sorted_dy.begin(), sorted_dy.end());
         med = (N & 1) ? sorted_dy[N / 2] : 0.5 * (sorted_dy[N / 2 - 1] + sorted_dy[N / 2]);
     }
+    // distinct observation times (exact equality): the thermal state depends on (walker, time) only
+    std::vector<double> epochs(ht);
+    std::sort(epochs.begin(), epochs.end());
+    epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
+    std::vector<int> hepoch(N);
+    for (int i = 0; i < N; ++i)
+        hepoch[i] = (int)(std::lower_bound(epochs.begin(), epochs.end(), ht[i]) - epochs.begin());
+    const bool all_finite_t = std::all_of(ht.begin(), ht.end(), [](double v) { return std::isfinite(v); });
     const int n_chunks = std::max(1, (N + kBlock - 1) / kBlock);
     std::vector<int> clo(n_chunks, 0), cn(n_chunks, 0);
     int max_cn = 0;
@@ -588,6 +673,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
     dp.tab_in_lds = max_cn <= kLdsTabMax;
+    dp.n_epochs = (int)epochs.size();
+    dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
     dp.variant = 1;
     std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
     dp.log_norm_const = lognorm;
@@ -602,9 +689,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
     UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hoff, doff); UP(hcnt, dcnt); UP(hfilt, dfilt); UP(horig, dorig);
     UP(clo, dclo); UP(cn, dcn); UP(htab, dtab); UP(htaboff, e->d_tab_off);
-    int* dcord;
-    double* dexp;
-    UP(corder, dcord); UP(hexp, dexp);
+    int *dcord, *depoch;
+    double *dexp, *depocht;
+    UP(corder, dcord); UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
+    dp.pt_epoch = depoch;
+    dp.epoch_t = depocht;
     dp.chunk_order = dcord;
     dp.exp2tab = dexp;
     if (companion) {
@@ -681,9 +770,9 @@ static lcf_status evaluate_impl(lcf_engine* e, int64_t n, const double* P, doubl
         double* b0 = e->wbig;
         double* b1 = e->wbig + per * N;
         if (mode == 1)
-            launch_points<1>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, b0, nullptr, e->stream);
+            launch_points<1>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, e->wtherm, b0, nullptr, e->stream);
         else
-            launch_points<2>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, b0, b1, e->stream);
+            launch_points<2>(e, (int)lo, (int)m, e->wP, e->wcoef, e->wlprior, e->wtherm, b0, b1, e->stream);
         LCF_HIP(hipGetLastError());
         LCF_HIP(hipMemcpyAsync(o0 + lo * N, b0, m * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         if (mode == 2) LCF_HIP(hipMemcpyAsync(o1 + lo * N, b1, m * N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -736,12 +825,13 @@ extern "C" lcf_status lcf_profile_loglike_kernel(lcf_engine* e, int64_t n, const
     LCF_HIP(hipMemcpyAsync(e->wP, P, n * e->dp.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->dp, (int)n, e->wP,
                        e->wcoef, e->wlprior, 0);
-    launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wpart, nullptr, e->stream);  // warm-up
+    launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wtherm, e->wpart, nullptr, e->stream);  // warm-up (+ thermal states)
     hipEvent_t a, b;
     LCF_HIP(hipEventCreate(&a));
     LCF_HIP(hipEventCreate(&b));
     LCF_HIP(hipEventRecord(a, e->stream));
-    for (int r = 0; r < reps; ++r) launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wpart, nullptr, e->stream);
+    for (int r = 0; r < reps; ++r)
+        launch_points<0>(e, 0, (int)n, e->wP, e->wcoef, e->wlprior, e->wtherm, e->wpart, nullptr, e->stream, false);
     LCF_HIP(hipEventRecord(b, e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));
     float ms = 0.f;
@@ -761,12 +851,14 @@ struct lcf_sampler {
     DevSampler ds{};
     std::vector<void*> owned;
     double *coef = nullptr, *lprior = nullptr, *part = nullptr;
+    double2* therm = nullptr;
     int* d_perm = nullptr;
     int64_t perm_rows = 0;       // rows allocated
     bool have_perm = false;
     int64_t run_first = 0, run_steps = 0;
     int64_t chain_cap = 0;
     bool has_state = false;
+    bool force_unfused = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.;
 
@@ -798,10 +890,10 @@ lcf_status sampler_half(lcf_sampler* s, int64_t step, int half, int lo, int hi, 
     const int64_t row = step - s->run_first;
     const int* perm = s->have_perm ? s->d_perm + (size_t)row * ds.n_walkers : nullptr;
     if (do_propose)
-        hipLaunchKernelGGL(k_propose, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, e->dp, ds, perm, (long long)step,
-                           (long long)row, half, s->coef, s->lprior);
+        hipLaunchKernelGGL(k_propose, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, e->dp, ds, perm, (long long)step, half,
+                           s->coef, s->lprior);
     if (do_eval && hi > lo) {
-        launch_points<0>(e, lo, hi - lo, ds.Q, s->coef, s->lprior, s->part, nullptr, st);
+        launch_points<0>(e, lo, hi - lo, ds.Q, s->coef, s->lprior, s->therm, s->part, nullptr, st);
         hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
                            s->part + (size_t)lo * e->dp.n_chunks, s->lprior + lo, ds.newlp + lo);
     }
@@ -836,6 +928,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.Q, nh * nd); AL(ds.zl, nh); AL(ds.lnu, nh); AL(ds.act, nh);
     AL(ds.newlp, nh); AL(ds.nacc, nw); AL(ds.err, 1);
     AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_chunks);
+    if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
     hipMemset(ds.nacc, 0, nw * sizeof(long long));
     hipMemset(ds.err, 0, sizeof(int));
@@ -969,9 +1062,31 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
     if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     hipStream_t st = s->e->stream;
     LCF_HIP(hipEventRecord(s->ev0, st));
-    for (int64_t k = 0; k < n_steps; ++k)
-        for (int half = 0; half < 2; ++half)
-            if (lcf_status r = sampler_half(s, first_step + k, half, 0, s->ds.n_half, st, true, true, true)) return r;
+    if (s->ds.n_half <= 1024 && !s->force_unfused) {
+        // propose(k, h) fused with accept of the previous half-step: glue -> points, glue -> points, ..., glue
+        const DevSampler& ds = s->ds;
+        bool have_prev = false;
+        long long prev_row = 0;
+        for (int64_t k = 0; k <= n_steps; ++k) {
+            for (int half = 0; half < 2; ++half) {
+                const bool have_next = k < n_steps;
+                if (!have_prev && !have_next) break;
+                const int* perm = (s->have_perm && have_next) ? s->d_perm + (size_t)k * ds.n_walkers : nullptr;
+                hipLaunchKernelGGL(k_glue, dim3(1), dim3(1024), 0, st, s->e->dp, ds, have_prev ? 1 : 0, prev_row,
+                                   have_next ? 1 : 0, perm, (long long)(first_step + k), half, s->coef, s->lprior,
+                                   s->part);
+                if (!have_next) { have_prev = false; break; }
+                launch_points<0>(s->e, 0, ds.n_half, ds.Q, s->coef, s->lprior, s->therm, s->part, nullptr, st);
+                have_prev = true;
+                prev_row = k;
+            }
+        }
+        LCF_HIP(hipGetLastError());
+    } else {
+        for (int64_t k = 0; k < n_steps; ++k)
+            for (int half = 0; half < 2; ++half)
+                if (lcf_status r = sampler_half(s, first_step + k, half, 0, s->ds.n_half, st, true, true, true)) return r;
+    }
     LCF_HIP(hipEventRecord(s->ev1, st));
     LCF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;

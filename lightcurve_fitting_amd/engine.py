@@ -100,6 +100,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    try:
+        # PyTorch ships its own HIP/HSA runtime.  Two runtimes in one process do not coexist, so when torch is
+        # installed it is loaded FIRST and this library binds to the runtime already in the process (same soname).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise OSError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
                       f'`make -C {os.path.dirname(path)}` (hipcc --offload-arch=gfx950). There is no CPU fallback.')

@@ -88,7 +88,7 @@ class NativeBackend:
 class ShardedStretchDriver:
     """Runs half-steps over a backend, sharding the likelihood evaluation over the ranks of a process group."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, force_collective=False):
         import torch.distributed as dist
         self.backend = backend
         self.dist = dist
@@ -96,7 +96,8 @@ class ShardedStretchDriver:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.width = shard_bounds(backend.n_half, self.world, self.rank)
-        if self.world > 1:
+        self.collective = self.world > 1 or force_collective
+        if self.collective:
             self._send = backend.empty(self.width)
             self._recv = backend.empty(self.width * self.world)
 
@@ -109,7 +110,7 @@ class ShardedStretchDriver:
             for half in (0, 1):
                 b.propose(step, half)
                 b.evaluate(self.lo, self.hi)
-                if self.world > 1:
+                if self.collective:
                     newlp = b.newlp()
                     n = self.hi - self.lo
                     if n:
@@ -139,7 +140,8 @@ class EnsembleSampler:
         Fresh random red/blue colouring every step, as emcee's ``RedBlueMove`` does.
     """
 
-    def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None):
+    def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None,
+                 force_sharded=False):
         from .engine import NativeSampler
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError('nwalkers must be even and at least 2 * ndim (emcee requirement)')
@@ -151,6 +153,7 @@ class EnsembleSampler:
         self.randomize_split = randomize_split
         self._native = NativeSampler(engine, nwalkers, seed, a)
         self._group = group
+        self._force_sharded = force_sharded  # run the phase-by-phase collective path even with a single rank
         self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
         self._chain = np.empty((0, nwalkers, ndim))
         self._lp = np.empty((0, nwalkers))
@@ -162,7 +165,9 @@ class EnsembleSampler:
             import torch.distributed as dist
         except ImportError:
             return False
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self._force_sharded or dist.get_world_size(self._group) > 1
 
     # --- emcee surface -------------------------------------------------------------------------------------------
     def reset(self):
@@ -196,8 +201,8 @@ class EnsembleSampler:
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         try:
             if self._distributed():
-                ShardedStretchDriver(NativeBackend(self._native), self._group).run(self._steps_done, nsteps, split,
-                                                                                  store)
+                ShardedStretchDriver(NativeBackend(self._native), self._group,
+                                     force_collective=self._force_sharded).run(self._steps_done, nsteps, split, store)
             else:
                 self._native.run(self._steps_done, nsteps, split, store)
         except Exception as exc:

@@ -128,3 +128,30 @@ def test_lightcurve_mcmc_end_to_end():
                          p_up=np.append(hi, 1.), nwalkers=32, nsteps=10, nsteps_burnin=10, use_sigma=True,
                          sigma_type='absolute')
     assert s2.chain.shape == (32, 10, 6) and m2.input_names[-1] == '\\sigma'
+
+
+def test_collective_path_single_rank_nccl():
+    """The multi-GPU code path (torch.distributed over RCCL, device buffers aliased into torch, all-gather of the new
+    log-probabilities) with one rank: must reproduce the fused native run bit for bit."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    pb, lc, m, eng, x0 = _setup(32)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        a = EnsembleSampler(32, 5, eng, seed=4242, force_sharded=True)
+        a.run_mcmc(x0, 8)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    b = EnsembleSampler(32, 5, eng, seed=4242)
+    b.run_mcmc(x0, 8)
+    assert np.array_equal(a.get_chain(), b.get_chain())
+    assert np.array_equal(a.get_log_prob(), b.get_log_prob())
