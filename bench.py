@@ -61,6 +61,23 @@ def initial_walkers(n):
     return rng.uniform(lo, hi, (n, 5))
 
 
+def committed_pmc():
+    """HBM traffic and VALU utilisation of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_k_points_summary.json, collected by tools/collect_profiles.sh; counters cannot be read from
+    inside this process).  FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads
+    prescribes (MI355X_MICROARCH.md, HBM section); both are in KiB per launch of 512 walkers."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_k_points_summary.json')
+    try:
+        c = {k: v['mean_per_launch'] for k, v in json.load(open(path)).items()}
+        traffic = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.
+        # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; SQ counters sample
+        # SQ_WAVES / launched waves of the grid
+        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 12 * 4))
+        return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+    except Exception:
+        return None, None, None
+
+
 def cpu_baseline(lc, budget_s=12., max_evals=128):
     """Reference-shaped CPU evaluation (per-walker call, per-point Python loop, K-sample trapezoid) on one core."""
     from oracle import lcf_oracle as O   # checker only: never on the product path
@@ -137,6 +154,7 @@ def main():
         evals_per_s = shard / (kern_ms * 1e-3)
         achieved = evals_per_s * ALG_INSTR / 1e12
         hbm_gbs = evals_per_s * ALG_BYTES / 1e9
+        traffic, valu_util, valu_per_wave = committed_pmc()
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -149,8 +167,12 @@ def main():
             'roofline': {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR,
                          'unit': 'Tinstr/s', 'frac': achieved / PEAK_FP64_TINSTR,
                          'note': 'FP64 vector-ALU lane-instructions: algorithmic 34 per Planck sample + 68 per point '
-                                 '(SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 TFLOP/s FMA',
-                         'traffic': None, 'kernel': 'k_points<variant,0,lds>', 'kernel_ms': kern_ms,
+                                 '(SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 TFLOP/s FMA. frac can exceed 1: the '
+                                 'kernel spends ~15 FP64 + 4 int32 instructions per sample, not the 34 of the convention; '
+                                 'valu_utilisation_pmc is the measured busy fraction of the vector ALU',
+                         'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
+                         'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
+                         'kernel': 'k_points<1,0,true,true>', 'kernel_ms': kern_ms,
                          'walkers_per_launch': shard,
                          'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                  'frac': hbm_gbs / PEAK_HBM_GBS, 'algorithmic_bytes_per_walker_step': ALG_BYTES}},

@@ -97,7 +97,10 @@ class ShardedStretchDriver:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi, self.width = shard_bounds(backend.n_half, self.world, self.rank)
         self.collective = self.world > 1 or force_collective
-        if self.collective:
+        # equal shards: the all-gather runs IN PLACE on the native newlp buffer (rank r's input is the slice
+        # [r*width, (r+1)*width) of the output) -- no staging copies, one collective per half-step
+        self.in_place = backend.n_half == self.width * self.world
+        if self.collective and not self.in_place:
             self._send = backend.empty(self.width)
             self._recv = backend.empty(self.width * self.world)
 
@@ -110,7 +113,10 @@ class ShardedStretchDriver:
             for half in (0, 1):
                 b.propose(step, half)
                 b.evaluate(self.lo, self.hi)
-                if self.collective:
+                if self.collective and self.in_place:
+                    newlp = b.newlp()
+                    self.dist.all_gather_into_tensor(newlp, newlp[self.lo:self.hi], group=self.group)
+                elif self.collective:
                     newlp = b.newlp()
                     n = self.hi - self.lo
                     if n:

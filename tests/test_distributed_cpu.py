@@ -36,11 +36,11 @@ def _worker(rank, world, port, nwalkers, nsteps, seed, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_chain_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize('world,nwalkers', [(2, 14), (3, 14), (2, 16)])  # uneven shards, and the in-place gather
+def test_sharded_chain_equals_single_process(tmp_path, world, nwalkers):
     import torch.multiprocessing as mp
     from oracle import lcf_oracle as O
-    nwalkers, nsteps, seed = 14, 6, 2024
+    nsteps, seed = 6, 2024
     mp.spawn(_worker, args=(world, _free_port(), nwalkers, nsteps, seed, str(tmp_path)), nprocs=world, join=True)
     chains = [np.load(tmp_path / f'chain_{r}.npy') for r in range(world)]
     for c in chains[1:]:
