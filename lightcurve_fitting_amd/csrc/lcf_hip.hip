@@ -217,20 +217,32 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
 }
 
 // ---- ensemble sampler ---------------------------------------------------------------------------------------------
+// Half-steps are numbered globally (g = 0, 1, 2, ...).  Everything a proposal needs later for its accept/reject is
+// kept per proposal slot in buffers double-buffered by the parity of g, so that ONE kernel (k_next) can, fully in
+// parallel and without any inter-workgroup hand-off, (i) commit the previous half-step and (ii) draw the next
+// proposals: a thread that needs the position of a walker whose previous move is not committed yet simply evaluates
+// that walker's accept test itself (a pure function of immutable per-slot data).
 struct DevSampler {
     int n_walkers, n_half, n_dim, store_chain;
     uint32_t key0, key1;
+    int inline_finalize;  // 1: accept tests sum the chi^2 partials themselves; 0: they read the gathered newlp
+    int pad;
     double a;
-    double* X;        // [n_walkers][n_dim]
-    double* LP;       // [n_walkers]
-    double* Q;        // [n_half][n_dim]
-    double* zl;       // [n_half] (n_dim - 1) ln z
-    double* lnu;      // [n_half]
-    int* act;         // [n_half] walker ids of the active half
-    double* newlp;    // [n_half]
-    double* chain;    // [n_steps][n_walkers][n_dim]
-    double* chain_lp; // [n_steps][n_walkers]
-    long long* nacc;  // [n_walkers]
+    double* X;          // [n_walkers][n_dim]  committed positions
+    double* LP;         // [n_walkers]         committed log-posteriors
+    double* Q[2];       // [n_half][n_dim]     proposals
+    double* zl[2];      // [n_half]            (n_dim - 1) ln z
+    double* lnu[2];     // [n_half]            ln u of the accept test
+    double* lp_old[2];  // [n_half]            log-posterior of the walker when the proposal was drawn
+    double* lpri[2];    // [n_half]            log-prior of the proposal
+    double* newlp[2];   // [n_half]            log-posterior of the proposal (finalize kernel / all-gather)
+    int* act[2];        // [n_half]            walker id of each slot
+    int* last_slot[2];     // [n_walkers]      slot of the walker's latest proposal among half-steps of this parity
+    long long* last_g[2];  // [n_walkers]      ... and the half-step it belongs to (-1: none)
+    const double* part; // [n_half][n_chunks]  chi^2 partial sums of the latest evaluation
+    double* chain;      // [n_steps][n_walkers][n_dim]
+    double* chain_lp;   // [n_steps][n_walkers]
+    long long* nacc;    // [n_walkers]
     int* err;
 };
 
@@ -273,10 +285,72 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
         perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
 }
 
-// Stretch-move proposal of active walker slot i + the proposal's derived coefficients and log-prior.
+// lnL + log-prior of proposal i from its partial sums (fixed order).
+__device__ inline double finalize_one(const DevProblem& pb, const double* __restrict__ part,
+                                      const double* __restrict__ lprior, int i) {
+    const double lp = lprior[i];
+    if (lp == -INFINITY) return -INFINITY;
+    double s = pb.use_sigma ? 0. : pb.log_norm_const;
+    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)i * pb.n_chunks + k];
+    return lp - 0.5 * s;
+}
+
+// Accept test of proposal `slot` of the half-step with parity pp: emcee's  (ndim-1) ln z + lp_new - lp_old > ln u.
+__device__ inline bool decide(const DevProblem& pb, const DevSampler& sm, int pp, int slot, double& nlp) {
+    nlp = sm.inline_finalize ? finalize_one(pb, sm.part, sm.lpri[pp], slot) : sm.newlp[pp][slot];
+    return (sm.zl[pp][slot] + nlp - sm.lp_old[pp][slot]) > sm.lnu[pp][slot];
+}
+
+// Position and log-posterior of walker w after half-step g - 1, committed or not.
+__device__ inline void current_state(const DevProblem& pb, const DevSampler& sm, long long g, int w, double* x,
+                                     double& lp) {
+    const double* src = sm.X + (size_t)w * sm.n_dim;
+    lp = sm.LP[w];
+    const int pp = (int)((g - 1) & 1);
+    if (sm.last_g[pp][w] == g - 1) {  // written by half-step g - 1's kernel, never by the running one
+        const int slot = sm.last_slot[pp][w];
+        double nlp;
+        if (decide(pb, sm, pp, slot, nlp)) {
+            src = sm.Q[pp] + (size_t)slot * sm.n_dim;
+            lp = nlp;
+        } else {
+            lp = sm.lp_old[pp][slot];
+        }
+    }
+    for (int d = 0; d < sm.n_dim; ++d) x[d] = src[d];
+}
+
+// Commit proposal `slot` of half-step g_prev: state, acceptance count, chain row.
+__device__ inline void commit_one(const DevProblem& pb, const DevSampler& sm, long long g_prev, long long chain_row,
+                                  int slot) {
+    const int pp = (int)(g_prev & 1);
+    const int wid = sm.act[pp][slot];
+    double nlp;
+    const bool ok = decide(pb, sm, pp, slot, nlp);
+    if (nlp != nlp) atomicExch(sm.err, 1);
+    double lp = sm.lp_old[pp][slot];
+    double* xw = sm.X + (size_t)wid * sm.n_dim;
+    if (ok) {
+        const double* q = sm.Q[pp] + (size_t)slot * sm.n_dim;
+        for (int d = 0; d < sm.n_dim; ++d) xw[d] = q[d];
+        sm.LP[wid] = nlp;
+        sm.nacc[wid] += 1;
+        lp = nlp;
+    }
+    if (sm.store_chain) {
+        double* row = sm.chain + ((size_t)chain_row * sm.n_walkers + wid) * sm.n_dim;
+        for (int d = 0; d < sm.n_dim; ++d) row[d] = xw[d];
+        sm.chain_lp[(size_t)chain_row * sm.n_walkers + wid] = lp;
+    }
+}
+
+// Stretch-move proposal of slot i of half-step g (+ its derived coefficients and log-prior).  `publish`: write the
+// per-slot records to global memory (exactly one thread per slot does).
 __device__ inline void propose_one(const DevProblem& pb, const DevSampler& sm, const int* __restrict__ perm,
-                                   long long step, int half, int i, double* __restrict__ coef,
+                                   long long g, long long step, int half, int i, bool publish,
+                                   double* __restrict__ c, double& lprior_out, double* __restrict__ coef,
                                    double* __restrict__ lprior) {
+    const int cp = (int)(g & 1);
     const int n_other = sm.n_walkers - sm.n_half;
     const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
     const int wid = perm ? perm[my_slot] : my_slot;
@@ -290,80 +364,66 @@ __device__ inline void propose_one(const DevProblem& pb, const DevSampler& sm, c
     j = min(j, n_other - 1);
     const int other_slot = half == 0 ? sm.n_half + j : j;
     const int pid = perm ? perm[other_slot] : other_slot;
-    double q[kMaxDim];
-    for (int d = 0; d < sm.n_dim; ++d) {
-        const double cj = sm.X[(size_t)pid * sm.n_dim + d];
-        const double xi = sm.X[(size_t)wid * sm.n_dim + d];
-        q[d] = cj - (cj - xi) * z;
-        sm.Q[(size_t)i * sm.n_dim + d] = q[d];
-    }
-    sm.act[i] = wid;
-    sm.zl[i] = (double)(sm.n_dim - 1) * log(z);
-    sm.lnu[i] = log(u01(s[0], s[1]));
-    double c[kNCoef];
+    double xi[kMaxDim], cj[kMaxDim], q[kMaxDim], lp_i, lp_j;
+    current_state(pb, sm, g, wid, xi, lp_i);
+    current_state(pb, sm, g, pid, cj, lp_j);
+    for (int d = 0; d < sm.n_dim; ++d) q[d] = cj[d] - (cj[d] - xi[d]) * z;
     walker_coefficients(pb, q, c);
-    for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
-    lprior[i] = walker_log_prior(pb, q);
-}
-
-// lnL + log-prior of proposal i from its partial sums (fixed order).
-__device__ inline double finalize_one(const DevProblem& pb, const double* __restrict__ part,
-                                      const double* __restrict__ lprior, int i) {
-    const double lp = lprior[i];
-    if (lp == -INFINITY) return -INFINITY;
-    double s = pb.use_sigma ? 0. : pb.log_norm_const;
-    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)i * pb.n_chunks + k];
-    return lp - 0.5 * s;
-}
-
-// Accept / reject of active walker slot i given its new log-posterior; chain bookkeeping.
-__device__ inline void accept_one(const DevSampler& sm, long long chain_row, int i, double nlp) {
-    const int wid = sm.act[i];
-    const double old = sm.LP[wid];
-    if (nlp != nlp) atomicExch(sm.err, 1);
-    const bool ok = (sm.zl[i] + nlp - old) > sm.lnu[i];
-    double lp = old;
-    if (ok) {
-        for (int d = 0; d < sm.n_dim; ++d) sm.X[(size_t)wid * sm.n_dim + d] = sm.Q[(size_t)i * sm.n_dim + d];
-        sm.LP[wid] = nlp;
-        sm.nacc[wid] += 1;
-        lp = nlp;
-    }
-    if (sm.store_chain) {
-        double* row = sm.chain + ((size_t)chain_row * sm.n_walkers + wid) * sm.n_dim;
-        for (int d = 0; d < sm.n_dim; ++d) row[d] = sm.X[(size_t)wid * sm.n_dim + d];
-        sm.chain_lp[(size_t)chain_row * sm.n_walkers + wid] = lp;
+    lprior_out = walker_log_prior(pb, q);
+    if (publish) {
+        for (int d = 0; d < sm.n_dim; ++d) sm.Q[cp][(size_t)i * sm.n_dim + d] = q[d];
+        sm.act[cp][i] = wid;
+        sm.zl[cp][i] = (double)(sm.n_dim - 1) * log(z);
+        sm.lnu[cp][i] = log(u01(s[0], s[1]));
+        sm.lp_old[cp][i] = lp_i;
+        sm.lpri[cp][i] = lprior_out;
+        sm.last_slot[cp][wid] = i;
+        sm.last_g[cp][wid] = g;
+        for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
+        lprior[i] = lprior_out;
     }
 }
 
-__global__ void k_propose(const DevProblem pb, const DevSampler sm, const int* __restrict__ perm, long long step,
-                          int half, double* __restrict__ coef, double* __restrict__ lprior) {
+// One thread per proposal slot: commit half-step g - 1 (if any) and draw half-step g (if any).
+__global__ __launch_bounds__(64) void k_next(const DevProblem pb, const DevSampler sm, int have_prev,
+                                             long long prev_row, int have_next, const int* __restrict__ perm,
+                                             long long g, long long step, int half, double* __restrict__ coef,
+                                             double* __restrict__ lprior) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < sm.n_half) propose_one(pb, sm, perm, step, half, i, coef, lprior);
-}
-
-// Reads the (gathered) new log-posteriors.
-__global__ void k_accept(const DevSampler sm, long long chain_row) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < sm.n_half) accept_one(sm, chain_row, i, sm.newlp[i]);
-}
-
-// Single-GPU fast path for ensembles of up to 2048 walkers: ONE workgroup finishes the previous half-step
-// (fixed-order sum of the partials, accept/reject) and, after a workgroup barrier, draws the proposals of the next
-// one.  Replaces three latency-bound launches (finalize, accept, propose) per half-step by one.
-__global__ __launch_bounds__(1024) void k_glue(const DevProblem pb, const DevSampler sm, int have_prev,
-                                               long long prev_row, int have_next, const int* __restrict__ perm,
-                                               long long step, int half, double* __restrict__ coef,
-                                               double* __restrict__ lprior, const double* __restrict__ part) {
-    const int i = threadIdx.x;
-    if (have_prev && i < sm.n_half) {
-        const double nlp = finalize_one(pb, part, lprior, i);
-        sm.newlp[i] = nlp;
-        accept_one(sm, prev_row, i, nlp);
+    if (i >= sm.n_half) return;
+    if (have_prev) commit_one(pb, sm, g - 1, prev_row, i);
+    if (have_next) {
+        double c[kNCoef], lp;
+        propose_one(pb, sm, perm, g, step, half, i, true, c, lp, coef, lprior);
     }
-    __threadfence_block();
-    __syncthreads();  // every accepted position is visible before any partner is read
-    if (have_next && i < sm.n_half) propose_one(pb, sm, perm, step, half, i, coef, lprior);
+}
+
+// Same, fused with the thermal-state precompute: workgroup (slot i, epoch chunk): thread 0 commits/draws (only the
+// chunk-0 workgroup publishes), then all 256 threads evaluate the thermal state of their epochs for the proposal.
+// Slots outside [lo, hi) (other ranks' shards) skip the thermal part.
+__global__ __launch_bounds__(kBlock) void k_next_thermal(const DevProblem pb, const DevSampler sm, int have_prev,
+                                                         long long prev_row, const int* __restrict__ perm,
+                                                         long long g, long long step, int half, int lo, int hi,
+                                                         int n_echunks, double* __restrict__ coef,
+                                                         double* __restrict__ lprior, double2* __restrict__ therm) {
+    __shared__ double sc[kNCoef + 1];
+    const int i = blockIdx.x / n_echunks, ec = blockIdx.x % n_echunks;
+    const bool in_shard = i >= lo && i < hi;
+    if (ec > 0 && !in_shard) return;
+    if (threadIdx.x == 0) {
+        if (have_prev && ec == 0) commit_one(pb, sm, g - 1, prev_row, i);
+        double c[kNCoef], lp;
+        propose_one(pb, sm, perm, g, step, half, i, ec == 0, c, lp, coef, lprior);
+        for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
+        sc[kNCoef] = lp;
+    }
+    __syncthreads();
+    if (!in_shard || sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
+    const int ep = ec * kBlock + threadIdx.x;
+    if (ep >= pb.n_epochs) return;
+    double T, pref;
+    thermal_state(pb, sc, pb.epoch_t[ep], T, pref);
+    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T, pref);
 }
 
 }  // namespace
@@ -853,12 +913,14 @@ struct lcf_sampler {
     double *coef = nullptr, *lprior = nullptr, *part = nullptr;
     double2* therm = nullptr;
     int* d_perm = nullptr;
-    int64_t perm_rows = 0;       // rows allocated
+    int64_t perm_rows = 0;  // rows allocated
     bool have_perm = false;
     int64_t run_first = 0, run_steps = 0;
     int64_t chain_cap = 0;
     bool has_state = false;
-    bool force_unfused = false;
+    long long g_next = 2;     // global half-step counter (never reused: see lcf_sampler_begin)
+    long long g_run0 = 2;     // first half-step of the current run
+    bool pending = false;     // the last proposed half-step is not committed yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.;
 
@@ -882,25 +944,56 @@ lcf_status dalloc(T** p, size_t n, std::vector<void*>& owned) {
     return LCF_OK;
 }
 
-lcf_status sampler_half(lcf_sampler* s, int64_t step, int half, int lo, int hi, hipStream_t st, bool do_propose,
-                        bool do_eval, bool do_accept) {
+const int* perm_row(const lcf_sampler* s, long long g) {
+    if (!s->have_perm) return nullptr;
+    return s->d_perm + (size_t)((g - s->g_run0) / 2) * s->ds.n_walkers;
+}
+
+// Commit half-step g_next - 1 (if pending) and draw half-step g_next (if have_next).  `fuse_thermal`: also evaluate
+// the thermal states of slots [lo, hi) in the same launch.
+lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo, int hi, hipStream_t st) {
     lcf_engine* e = s->e;
     const DevSampler& ds = s->ds;
-    const int nh = ds.n_half, bs = 128;
-    const int64_t row = step - s->run_first;
-    const int* perm = s->have_perm ? s->d_perm + (size_t)row * ds.n_walkers : nullptr;
-    if (do_propose)
-        hipLaunchKernelGGL(k_propose, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, e->dp, ds, perm, (long long)step, half,
-                           s->coef, s->lprior);
-    if (do_eval && hi > lo) {
-        launch_points<0>(e, lo, hi - lo, ds.Q, s->coef, s->lprior, s->therm, s->part, nullptr, st);
-        hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
-                           s->part + (size_t)lo * e->dp.n_chunks, s->lprior + lo, ds.newlp + lo);
+    const long long g = s->g_next;
+    const int have_prev = s->pending ? 1 : 0;
+    if (!have_prev && !have_next) return LCF_OK;
+    const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
+    const long long rel = g - s->g_run0;
+    const long long step = s->run_first + rel / 2;
+    const int half = (int)(rel & 1);
+    const int* perm = have_next ? perm_row(s, g) : nullptr;
+    if (have_next && fuse_thermal && e->dp.use_therm) {
+        const int nec = (e->dp.n_epochs + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_next_thermal, dim3((unsigned)(ds.n_half * nec)), dim3(kBlock), 0, st, e->dp, ds, have_prev,
+                           prev_row, perm, g, step, half, lo, hi, nec, s->coef, s->lprior, s->therm);
+    } else {
+        hipLaunchKernelGGL(k_next, dim3((ds.n_half + 63) / 64), dim3(64), 0, st, e->dp, ds, have_prev, prev_row,
+                           have_next ? 1 : 0, perm, g, step, half, s->coef, s->lprior);
     }
-    if (do_accept)
-        hipLaunchKernelGGL(k_accept, dim3((nh + bs - 1) / bs), dim3(bs), 0, st, ds, (long long)row);
+    LCF_HIP(hipGetLastError());
+    s->pending = have_next;
+    if (have_next) s->g_next = g + 1;
+    return LCF_OK;
+}
+
+// Likelihood of the proposals [lo, hi) of the half-step drawn last.
+lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool finalize, hipStream_t st) {
+    lcf_engine* e = s->e;
+    if (hi <= lo) return LCF_OK;
+    launch_points<0>(e, lo, hi - lo, s->ds.Q[(s->g_next - 1) & 1], s->coef, s->lprior, s->therm, s->part, nullptr, st,
+                     !thermal_done);
+    if (finalize) {
+        const int bs = 128;
+        hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
+                           s->part + (size_t)lo * e->dp.n_chunks, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
+    }
     LCF_HIP(hipGetLastError());
     return LCF_OK;
+}
+
+lcf_status flush_pending(lcf_sampler* s, hipStream_t st) {
+    if (!s->pending) return LCF_OK;
+    return launch_next(s, false, false, 0, 0, st);
 }
 
 }  // namespace
@@ -925,15 +1018,24 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
     lcf_status st;
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
-    AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.Q, nh * nd); AL(ds.zl, nh); AL(ds.lnu, nh); AL(ds.act, nh);
-    AL(ds.newlp, nh); AL(ds.nacc, nw); AL(ds.err, 1);
+    AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.nacc, nw); AL(ds.err, 1);
+    for (int b = 0; b < 2; ++b) {
+        AL(ds.last_slot[b], nw); AL(ds.last_g[b], nw);
+        AL(ds.Q[b], nh * nd); AL(ds.zl[b], nh); AL(ds.lnu[b], nh); AL(ds.lp_old[b], nh); AL(ds.lpri[b], nh);
+        AL(ds.newlp[b], nh); AL(ds.act[b], nh);
+    }
     AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_chunks);
     if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
-    hipMemset(ds.nacc, 0, nw * sizeof(long long));
-    hipMemset(ds.err, 0, sizeof(int));
-    hipEventCreate(&s->ev0);
-    hipEventCreate(&s->ev1);
+    ds.part = s->part;
+    LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
+    LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
+    for (int b = 0; b < 2; ++b) {
+        LCF_HIP(hipMemset(ds.last_g[b], 0xff, nw * sizeof(long long)));  // -1: no proposal yet
+        LCF_HIP(hipMemset(ds.last_slot[b], 0, nw * sizeof(int)));
+    }
+    LCF_HIP(hipEventCreate(&s->ev0));
+    LCF_HIP(hipEventCreate(&s->ev1));
     *out = s;
     return LCF_OK;
 }
@@ -944,12 +1046,16 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     if (!s || !coords) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     lcf_engine* e = s->e;
     LCF_HIP(hipSetDevice(e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    s->pending = false;  // an uncommitted move of the old state is dropped with it
     const DevSampler& ds = s->ds;
     if (lcf_status st = e->reserve(ds.n_walkers)) return st;
     LCF_HIP(hipMemcpyAsync(ds.X, coords, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
     if (lcf_status st = logprob_dev(e, ds.n_walkers, ds.X, ds.LP, e->stream, 1)) return st;
     LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
+    for (int b = 0; b < 2; ++b)
+        LCF_HIP(hipMemsetAsync(ds.last_g[b], 0xff, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));
     s->has_state = true;
     return LCF_OK;
@@ -958,6 +1064,8 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
 lcf_status lcf_sampler_get_state(lcf_sampler* s, double* coords, double* log_prob) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
     LCF_HIP(hipDeviceSynchronize());
     const DevSampler& ds = s->ds;
     if (coords) LCF_HIP(hipMemcpy(coords, ds.X, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
@@ -979,9 +1087,14 @@ lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps
     lcf_engine* e = s->e;
     LCF_HIP(hipSetDevice(e->device));
     LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = flush_pending(s, e->stream)) return st;  // with the previous run's chain/perm settings
+    LCF_HIP(hipDeviceSynchronize());
     DevSampler& ds = s->ds;
     s->run_first = first_step;
     s->run_steps = n_steps;
+    // leave a gap in the half-step numbering: no stale (last_g == g - 1) match across runs or set_state calls
+    s->g_next += 2;
+    s->g_run0 = s->g_next;
     ds.store_chain = store_chain ? 1 : 0;
     if (store_chain && n_steps > s->chain_cap) {
         if (ds.chain) hipFree(ds.chain);
@@ -1031,25 +1144,36 @@ lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps
     return LCF_OK;
 }
 
+// ---- phase-by-phase API (multi-GPU): propose -> evaluate(shard) -> [all-gather newlp] -> accept -------------------
 lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void* stream) {
     if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
-    return sampler_half(s, step, half, 0, 0, stream ? (hipStream_t)stream : s->e->stream, true, false, false);
+    const long long g = s->g_run0 + 2 * (step - s->run_first) + half;
+    if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
+    s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
+    return launch_next(s, true, false, 0, 0, stream ? (hipStream_t)stream : s->e->stream);
 }
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
     if (!s || lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
-    return sampler_half(s, s->run_first, 0, lo, hi, stream ? (hipStream_t)stream : s->e->stream, false, true, false);
+    if (!s->pending) return fail(LCF_ERR_STATE, "lcf_sampler_propose must precede lcf_sampler_evaluate");
+    return launch_eval(s, lo, hi, false, true, stream ? (hipStream_t)stream : s->e->stream);
 }
 lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* stream) {
     if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
-    return sampler_half(s, step, half, 0, 0, stream ? (hipStream_t)stream : s->e->stream, false, false, true);
+    // The accept/reject of a half-step is applied by the kernel that draws the next one (it needs the gathered
+    // newlp, which is complete once this call is reached); only the run's last half-step is committed here.
+    if (step == s->run_first + s->run_steps - 1 && half == 1)
+        return flush_pending(s, stream ? (hipStream_t)stream : s->e->stream);
+    return LCF_OK;
 }
-void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp : nullptr; }
+void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
 
 lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
     LCF_HIP(hipDeviceSynchronize());
     int err = 0;
     LCF_HIP(hipMemcpy(&err, s->ds.err, sizeof(int), hipMemcpyDeviceToHost));
@@ -1061,32 +1185,14 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
                            const int32_t* perm, int32_t store_chain) {
     if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     hipStream_t st = s->e->stream;
+    s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
-    if (s->ds.n_half <= 1024 && !s->force_unfused) {
-        // propose(k, h) fused with accept of the previous half-step: glue -> points, glue -> points, ..., glue
-        const DevSampler& ds = s->ds;
-        bool have_prev = false;
-        long long prev_row = 0;
-        for (int64_t k = 0; k <= n_steps; ++k) {
-            for (int half = 0; half < 2; ++half) {
-                const bool have_next = k < n_steps;
-                if (!have_prev && !have_next) break;
-                const int* perm = (s->have_perm && have_next) ? s->d_perm + (size_t)k * ds.n_walkers : nullptr;
-                hipLaunchKernelGGL(k_glue, dim3(1), dim3(1024), 0, st, s->e->dp, ds, have_prev ? 1 : 0, prev_row,
-                                   have_next ? 1 : 0, perm, (long long)(first_step + k), half, s->coef, s->lprior,
-                                   s->part);
-                if (!have_next) { have_prev = false; break; }
-                launch_points<0>(s->e, 0, ds.n_half, ds.Q, s->coef, s->lprior, s->therm, s->part, nullptr, st);
-                have_prev = true;
-                prev_row = k;
-            }
-        }
-        LCF_HIP(hipGetLastError());
-    } else {
-        for (int64_t k = 0; k < n_steps; ++k)
-            for (int half = 0; half < 2; ++half)
-                if (lcf_status r = sampler_half(s, first_step + k, half, 0, s->ds.n_half, st, true, true, true)) return r;
+    // per half-step: [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
+    for (int64_t k = 0; k < 2 * n_steps; ++k) {
+        if (lcf_status r = launch_next(s, true, true, 0, s->ds.n_half, st)) return r;
+        if (lcf_status r = launch_eval(s, 0, s->ds.n_half, s->e->dp.use_therm != 0, false, st)) return r;
     }
+    if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
     LCF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
@@ -1100,6 +1206,8 @@ lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob
     if (!s->ds.store_chain || s->run_steps == 0) return fail(LCF_ERR_STATE, "no stored chain");
     LCF_HIP(hipSetDevice(s->e->device));
     LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
+    LCF_HIP(hipDeviceSynchronize());
     const DevSampler& ds = s->ds;
     if (chain)
         LCF_HIP(hipMemcpy(chain, ds.chain, (size_t)s->run_steps * ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
@@ -1111,6 +1219,8 @@ lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted) {
     if (!s || !n_accepted) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
     LCF_HIP(hipDeviceSynchronize());
     LCF_HIP(hipMemcpy(n_accepted, s->ds.nacc, (size_t)s->ds.n_walkers * sizeof(long long), hipMemcpyDeviceToHost));
     return LCF_OK;

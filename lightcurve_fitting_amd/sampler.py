@@ -47,7 +47,7 @@ class NativeBackend:
     def __init__(self, native_sampler):
         self.ns = native_sampler
         self.n_half = native_sampler.nwalkers // 2
-        self._newlp = None
+        self._newlp = {}
 
     def begin(self, first_step, nsteps, split, store):
         self.ns.begin(first_step, nsteps, split, store)
@@ -66,16 +66,18 @@ class NativeBackend:
         self.ns.accept(step, half, self.stream())
 
     def newlp(self):
-        """float64 torch tensor aliasing the native ``newlp[n_half]`` buffer."""
-        if self._newlp is None:
+        """float64 torch tensor aliasing the native ``newlp[n_half]`` buffer of the half-step drawn last (the native
+        side double-buffers it, so there are two aliases)."""
+        ptr = self.ns.newlp_ptr()
+        if ptr not in self._newlp:
             import torch
-            ptr, n = self.ns.newlp_ptr(), self.n_half
+            n = self.n_half
 
             class _Alias:
                 __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2,
                                             'strides': None}
-            self._newlp = torch.as_tensor(_Alias(), device=f'cuda:{self.ns.engine.device}')
-        return self._newlp
+            self._newlp[ptr] = torch.as_tensor(_Alias(), device=f'cuda:{self.ns.engine.device}')
+        return self._newlp[ptr]
 
     def empty(self, n):
         import torch
