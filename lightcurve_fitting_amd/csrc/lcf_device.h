@@ -200,7 +200,9 @@ __device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const E
 //   Companion:      c[1] = T coefficient, c[2] = R^2 coefficient, c[3] = t_peak, c[4] = stretch, c[5] = shock factor
 //   Blackbody:      c[1] = T, c[2] = R^2
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p, double* __restrict__ c) {
+// `lq[d]` = log(p[d]) for d < n_par (may be NaN/-inf where p[d] <= 0: only used when the parameter is positive).
+__device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p,
+                                           const double* __restrict__ lq, double* __restrict__ c) {
     const double* k = pb.consts;
     for (int i = 0; i < kNCoef; ++i) c[i] = 0.;
     switch (pb.model) {
@@ -210,7 +212,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[0] = p[4];
             if (v > 0. && M > 0. && f > 0. && R > 0. && v < 1e100 && M < 1e100 && f < 1e100 && R < 1e100) {
                 // all bases positive: every power() is a plain power; share the four logarithms
-                const double lv = log(v), lM = log(M), lf = log(f), lR = log(R);
+                const double lv = lq[0], lM = lq[1], lf = lq[2], lR = lq[3];
                 c[1] = (T0 * ratio / kKB) * exp(eps1 * (2. * lv - lf) + 0.25 * lR);
                 c[2] = (L0 * A) * exp(-eps2 * (lv - lf) + 2. * lv + lR);
                 c[3] = a > 0. ? alpha * (log(a / 19.5) - 0.5 * (lM - lv)) : qnan();
@@ -240,7 +242,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[0] = p[4];
             c[4] = k[6] * sqrt(M / v);
             if (v > 0. && f > 0. && R > 0. && v < 1e100 && f < 1e100 && R < 1e100) {
-                const double lv = log(v), lf = log(f), lR = log(R);
+                const double lv = lq[0], lf = lq[2], lR = lq[3];
                 const double ex = exp(-0.5447271754416722 * exp(0.03 * lf));  // 0.58 ** (f ** 0.03)
                 c[1] = (k[4] / kKB) * exp(-0.32 * lR + ex * lv);
                 c[2] = k[3] * exp(0.78 * lR + 2.11 * lv + 0.11 * lf);
@@ -259,7 +261,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             const double Mv = pb.model == kCompanion3 ? 1. : p[2];
             c[0] = p[0];
             if (a13 > 0. && Mv > 0. && a13 < 1e8 && a13 > 1e-8 && Mv < 1e100) {
-                const double la = log(a13), lm = log(Mv);
+                const double la = lq[1], lm = pb.model == kCompanion3 ? 0. : lq[2];
                 c[1] = 25. * exp((36. * la + lm) * (1. / 144.));
                 c[2] = 7.29 * exp(lm * (2. / 9.));
             } else {
@@ -284,6 +286,13 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
         default:
             break;
     }
+}
+
+// Convenience for one-thread-per-walker callers: logarithms computed in place.
+__device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p, double* __restrict__ c) {
+    double lq[kMaxDim];
+    for (int d = 0; d < pb.n_par; ++d) lq[d] = log(p[d]);
+    walker_coefficients(pb, p, lq, c);
 }
 
 // log-prior of one walker; -inf outside the strict bounds.  models.py:1055-1098, fitting.py:122-126

@@ -301,124 +301,112 @@ __device__ inline bool decide(const DevProblem& pb, const DevSampler& sm, int pp
     return (sm.zl[pp][slot] + nlp - sm.lp_old[pp][slot]) > sm.lnu[pp][slot];
 }
 
-// Position and log-posterior of walker w after half-step g - 1, committed or not.
-__device__ inline void current_state(const DevProblem& pb, const DevSampler& sm, long long g, int w, double* x,
-                                     double& lp) {
-    const double* src = sm.X + (size_t)w * sm.n_dim;
-    lp = sm.LP[w];
-    const int pp = (int)((g - 1) & 1);
-    if (sm.last_g[pp][w] == g - 1) {  // written by half-step g - 1's kernel, never by the running one
-        const int slot = sm.last_slot[pp][w];
-        double nlp;
-        if (decide(pb, sm, pp, slot, nlp)) {
-            src = sm.Q[pp] + (size_t)slot * sm.n_dim;
-            lp = nlp;
-        } else {
-            lp = sm.lp_old[pp][slot];
-        }
-    }
-    for (int d = 0; d < sm.n_dim; ++d) x[d] = src[d];
-}
-
-// Commit proposal `slot` of half-step g_prev: state, acceptance count, chain row.
-__device__ inline void commit_one(const DevProblem& pb, const DevSampler& sm, long long g_prev, long long chain_row,
-                                  int slot) {
-    const int pp = (int)(g_prev & 1);
-    const int wid = sm.act[pp][slot];
-    double nlp;
-    const bool ok = decide(pb, sm, pp, slot, nlp);
-    if (nlp != nlp) atomicExch(sm.err, 1);
-    double lp = sm.lp_old[pp][slot];
-    double* xw = sm.X + (size_t)wid * sm.n_dim;
-    if (ok) {
-        const double* q = sm.Q[pp] + (size_t)slot * sm.n_dim;
-        for (int d = 0; d < sm.n_dim; ++d) xw[d] = q[d];
-        sm.LP[wid] = nlp;
-        sm.nacc[wid] += 1;
-        lp = nlp;
-    }
-    if (sm.store_chain) {
-        double* row = sm.chain + ((size_t)chain_row * sm.n_walkers + wid) * sm.n_dim;
-        for (int d = 0; d < sm.n_dim; ++d) row[d] = xw[d];
-        sm.chain_lp[(size_t)chain_row * sm.n_walkers + wid] = lp;
-    }
-}
-
-// Stretch-move proposal of slot i of half-step g (+ its derived coefficients and log-prior).  `publish`: write the
-// per-slot records to global memory (exactly one thread per slot does).
-__device__ inline void propose_one(const DevProblem& pb, const DevSampler& sm, const int* __restrict__ perm,
-                                   long long g, long long step, int half, int i, bool publish,
-                                   double* __restrict__ c, double& lprior_out, double* __restrict__ coef,
-                                   double* __restrict__ lprior) {
-    const int cp = (int)(g & 1);
-    const int n_other = sm.n_walkers - sm.n_half;
-    const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
-    const int wid = perm ? perm[my_slot] : my_slot;
-    uint32_t r[4], s[4];
-    philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 0u, sm.key0, sm.key1, r);
-    philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 1u, sm.key0, sm.key1, s);
-    const double uz = u01(r[0], r[1]);
-    const double zr = (sm.a - 1.) * uz + 1.;
-    const double z = zr * zr / sm.a;
-    int j = (int)(u01(r[2], r[3]) * (double)n_other);
-    j = min(j, n_other - 1);
-    const int other_slot = half == 0 ? sm.n_half + j : j;
-    const int pid = perm ? perm[other_slot] : other_slot;
-    double xi[kMaxDim], cj[kMaxDim], q[kMaxDim], lp_i, lp_j;
-    current_state(pb, sm, g, wid, xi, lp_i);
-    current_state(pb, sm, g, pid, cj, lp_j);
-    for (int d = 0; d < sm.n_dim; ++d) q[d] = cj[d] - (cj[d] - xi[d]) * z;
-    walker_coefficients(pb, q, c);
-    lprior_out = walker_log_prior(pb, q);
-    if (publish) {
-        for (int d = 0; d < sm.n_dim; ++d) sm.Q[cp][(size_t)i * sm.n_dim + d] = q[d];
-        sm.act[cp][i] = wid;
-        sm.zl[cp][i] = (double)(sm.n_dim - 1) * log(z);
-        sm.lnu[cp][i] = log(u01(s[0], s[1]));
-        sm.lp_old[cp][i] = lp_i;
-        sm.lpri[cp][i] = lprior_out;
-        sm.last_slot[cp][wid] = i;
-        sm.last_g[cp][wid] = g;
-        for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
-        lprior[i] = lprior_out;
-    }
-}
-
-// One thread per proposal slot: commit half-step g - 1 (if any) and draw half-step g (if any).
-__global__ __launch_bounds__(64) void k_next(const DevProblem pb, const DevSampler sm, int have_prev,
-                                             long long prev_row, int have_next, const int* __restrict__ perm,
-                                             long long g, long long step, int half, double* __restrict__ coef,
-                                             double* __restrict__ lprior) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sm.n_half) return;
-    if (have_prev) commit_one(pb, sm, g - 1, prev_row, i);
-    if (have_next) {
-        double c[kNCoef], lp;
-        propose_one(pb, sm, perm, g, step, half, i, true, c, lp, coef, lprior);
-    }
-}
-
-// Same, fused with the thermal-state precompute: workgroup (slot i, epoch chunk): thread 0 commits/draws (only the
-// chunk-0 workgroup publishes), then all 256 threads evaluate the thermal state of their epochs for the proposal.
-// Slots outside [lo, hi) (other ranks' shards) skip the thermal part.
-__global__ __launch_bounds__(kBlock) void k_next_thermal(const DevProblem pb, const DevSampler sm, int have_prev,
-                                                         long long prev_row, const int* __restrict__ perm,
-                                                         long long g, long long step, int half, int lo, int hi,
-                                                         int n_echunks, double* __restrict__ coef,
-                                                         double* __restrict__ lprior, double2* __restrict__ therm) {
+// One workgroup per (proposal slot i, epoch chunk): wave 0 commits half-step g - 1 for slot i (chunk 0 only) and draws
+// slot i of half-step g COOPERATIVELY -- the latency chain of a single thread (three accept tests with dependent
+// loads, then six logarithms) is spread over lanes that run the same code on different data:
+//   lanes 0..2: accept test of {previous slot i, own walker, partner walker};  lanes 0..n_par+1: the logarithms of
+//   the proposal's parameters, of z and of u.
+// Every lane ends with the same proposal (bitwise); lane 0 of the chunk-0 workgroup publishes it.  Then all 256
+// threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
+__global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
+                                                 long long prev_row, int have_next, const int* __restrict__ perm,
+                                                 long long g, long long step, int half, int lo, int hi,
+                                                 int n_echunks, int do_thermal, double* __restrict__ coef,
+                                                 double* __restrict__ lprior, double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
     const int i = blockIdx.x / n_echunks, ec = blockIdx.x % n_echunks;
-    const bool in_shard = i >= lo && i < hi;
+    const bool in_shard = do_thermal && i >= lo && i < hi;
     if (ec > 0 && !in_shard) return;
-    if (threadIdx.x == 0) {
-        if (have_prev && ec == 0) commit_one(pb, sm, g - 1, prev_row, i);
-        double c[kNCoef], lp;
-        propose_one(pb, sm, perm, g, step, half, i, ec == 0, c, lp, coef, lprior);
-        for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
-        sc[kNCoef] = lp;
+    const int lane = threadIdx.x;
+    if (lane < 64) {
+        const int pp = (int)((g - 1) & 1), cp = (int)(g & 1), nd = sm.n_dim;
+        int wid = 0, pid = 0;
+        double z = 1., u = 0.5;
+        if (have_next) {
+            const int n_other = sm.n_walkers - sm.n_half;
+            const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
+            wid = perm ? perm[my_slot] : my_slot;
+            uint32_t r[4], s2[4];
+            philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 0u, sm.key0, sm.key1, r);
+            philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 1u, sm.key0, sm.key1, s2);
+            const double zr = (sm.a - 1.) * u01(r[0], r[1]) + 1.;
+            z = zr * zr / sm.a;
+            u = u01(s2[0], s2[1]);
+            int j = (int)(u01(r[2], r[3]) * (double)n_other);
+            j = min(j, n_other - 1);
+            const int other_slot = half == 0 ? sm.n_half + j : j;
+            pid = perm ? perm[other_slot] : other_slot;
+        }
+        // --- roles: which accept test (if any) this lane evaluates ---
+        int rw = -1, rslot = -1;
+        if (lane == 0 && have_prev && ec == 0) {
+            rslot = i;
+            rw = sm.act[pp][i];
+        } else if ((lane == 1 || lane == 2) && have_next) {
+            rw = lane == 1 ? wid : pid;
+            if (sm.last_g[pp][rw] == g - 1) rslot = sm.last_slot[pp][rw];
+        }
+        double nlp = 0.;
+        bool ok = false;
+        if (rslot >= 0) ok = decide(pb, sm, pp, rslot, nlp);
+        double row[kMaxDim], lp_cur = 0.;
+        for (int d = 0; d < kMaxDim; ++d) row[d] = 0.;
+        if (rw >= 0) {
+            const double* src = ok ? sm.Q[pp] + (size_t)rslot * nd : sm.X + (size_t)rw * nd;
+            for (int d = 0; d < nd; ++d) row[d] = src[d];
+            lp_cur = rslot >= 0 ? (ok ? nlp : sm.lp_old[pp][rslot]) : sm.LP[rw];
+        }
+        if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
+            if (nlp != nlp) atomicExch(sm.err, 1);
+            if (ok) {
+                for (int d = 0; d < nd; ++d) sm.X[(size_t)rw * nd + d] = row[d];
+                sm.LP[rw] = nlp;
+                sm.nacc[rw] += 1;
+            }
+            if (sm.store_chain) {
+                double* crow = sm.chain + ((size_t)prev_row * sm.n_walkers + rw) * nd;
+                for (int d = 0; d < nd; ++d) crow[d] = row[d];
+                sm.chain_lp[(size_t)prev_row * sm.n_walkers + rw] = lp_cur;
+            }
+        }
+        if (have_next) {
+            double q[kMaxDim], lq[kMaxDim];
+            double arg = 1.;
+            for (int d = 0; d < kMaxDim; ++d) {
+                const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
+                q[d] = d < nd ? cj - (cj - xi) * z : 0.;
+                if (lane == d && d < pb.n_par) arg = q[d];
+            }
+            const double lp_i = __shfl(lp_cur, 1, 64);
+            if (lane == pb.n_par) arg = z;
+            if (lane == pb.n_par + 1) arg = u;
+            const double lg = log(arg);  // one logarithm per lane, all at once
+            for (int d = 0; d < kMaxDim; ++d) lq[d] = __shfl(lg, d, 64);
+            const double lz = __shfl(lg, pb.n_par, 64), lu = __shfl(lg, pb.n_par + 1, 64);
+            double c[kNCoef];
+            walker_coefficients(pb, q, lq, c);
+            const double lpr = walker_log_prior(pb, q);
+            if (lane == 0) {
+                for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
+                sc[kNCoef] = lpr;
+                if (ec == 0) {  // publish the per-slot records
+                    for (int d = 0; d < nd; ++d) sm.Q[cp][(size_t)i * nd + d] = q[d];
+                    sm.act[cp][i] = wid;
+                    sm.zl[cp][i] = (double)(nd - 1) * lz;
+                    sm.lnu[cp][i] = lu;
+                    sm.lp_old[cp][i] = lp_i;
+                    sm.lpri[cp][i] = lpr;
+                    sm.last_slot[cp][wid] = i;
+                    sm.last_g[cp][wid] = g;
+                    for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
+                    lprior[i] = lpr;
+                }
+            }
+        }
     }
+    if (!have_next || !in_shard) return;
     __syncthreads();
-    if (!in_shard || sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
+    if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
     const int ep = ec * kBlock + threadIdx.x;
     if (ep >= pb.n_epochs) return;
     double T, pref;
@@ -962,14 +950,12 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const long long step = s->run_first + rel / 2;
     const int half = (int)(rel & 1);
     const int* perm = have_next ? perm_row(s, g) : nullptr;
-    if (have_next && fuse_thermal && e->dp.use_therm) {
-        const int nec = (e->dp.n_epochs + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(k_next_thermal, dim3((unsigned)(ds.n_half * nec)), dim3(kBlock), 0, st, e->dp, ds, have_prev,
-                           prev_row, perm, g, step, half, lo, hi, nec, s->coef, s->lprior, s->therm);
-    } else {
-        hipLaunchKernelGGL(k_next, dim3((ds.n_half + 63) / 64), dim3(64), 0, st, e->dp, ds, have_prev, prev_row,
-                           have_next ? 1 : 0, perm, g, step, half, s->coef, s->lprior);
-    }
+    const bool thermal = have_next && fuse_thermal && e->dp.use_therm;
+    const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
+    // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
+    hipLaunchKernelGGL(k_step, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, e->dp, ds,
+                       have_prev, prev_row, have_next ? 1 : 0, perm, g, step, half, lo, hi, nec, thermal ? 1 : 0,
+                       s->coef, s->lprior, s->therm);
     LCF_HIP(hipGetLastError());
     s->pending = have_next;
     if (have_next) s->g_next = g + 1;
