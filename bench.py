@@ -96,8 +96,46 @@ def cpu_baseline(lc, budget_s=12., max_evals=128):
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
 
 
+def run_sed(args):
+    """BASELINE configs[3]: per-epoch blackbody SED grid, 10 000 epochs x 6 filters (UBVgri) x 128 (T, R) candidates,
+    float32 arithmetic with the float64 kernel as the error reference.  Extra workload: prints its own JSON line."""
+    from lightcurve_fitting_amd import bolometric as B
+    from lightcurve_fitting_amd import models as M
+    rng = np.random.default_rng(SEED + 4)
+    n_ep, n_c = 10000, 128
+    Tt, Rt = rng.uniform(5., 50., n_ep), 10 ** rng.uniform(-1., 2., n_ep)
+    ytrue = M.blackbody_to_filters(BANDS, Tt, Rt)                     # (6, n_ep) on the GPU
+    y = ytrue.T * (1. + 0.03 * rng.standard_normal((n_ep, 6)))
+    epochs = [(BANDS, y[e], 0.03 * ytrue[:, e]) for e in range(n_ep)]
+    cand = np.stack([rng.uniform(1., 100., (n_ep, n_c)), 10 ** rng.uniform(-2., 3., (n_ep, n_c))], axis=-1)
+    like = B.SpectrumLikelihood(epochs, z=0.)
+    out = {}
+    for prec in ('f32', 'f64'):
+        res = like(cand, precision=prec)                              # warm-up
+        ms = []
+        for _ in range(max(3, args.steps // 20)):
+            res = like(cand, precision=prec)
+            ms.append(like.engine.last_kernel_ms)
+        out[prec] = (res, float(np.median(ms)))
+    samples = float(np.sum(like.samples_per_candidate)) * n_c          # real (zero-weight rows dropped)
+    alg_samples = n_ep * n_c * (13 + 11 + 15 + 89 + 75 + 89)
+    err = np.abs(out['f32'][0] - out['f64'][0]) / np.abs(out['f64'][0])
+    print(json.dumps({
+        'metric': 'SED candidate evaluations/sec', 'value': n_ep * n_c / (out['f32'][1] * 1e-3), 'unit': 'candidates/s',
+        'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic', 'higher_is_better': True, 'vs_baseline': None,
+        'config': {'workload': 'BASELINE configs[3]: 10000 epochs x 6 filters (UBVgri) x 128 (T,R) candidates',
+                   'planck_samples_per_launch': alg_samples},
+        'kernel_ms_f32': out['f32'][1], 'kernel_ms_f64': out['f64'][1],
+        'planck_samples_per_s_f32': alg_samples / (out['f32'][1] * 1e-3),
+        'planck_samples_per_s_f64': alg_samples / (out['f64'][1] * 1e-3),
+        'real_samples_per_launch': samples,
+        'f32_vs_f64_lnL_relative_error': {'max': float(err.max()), 'median': float(np.median(err))}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed'],
+                    help="'mcmc' (default) = the headline configs[1] line; 'sed' = configs[3] extra line")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
@@ -105,6 +143,9 @@ def main():
     ap.add_argument('--variant', type=int, default=1, help='band-sum variant: 1 fused (default), 0 libm')
     args = ap.parse_args()
 
+    if args.workload == 'sed':
+        import torch  # noqa: F401  (one HIP runtime per process: see engine.load_library)
+        return run_sed(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -177,6 +177,21 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
 void* lcf_sampler_newlp_ptr(lcf_sampler* s);
 lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGPROB if a NaN was seen */
 
+/* ---- per-epoch blackbody SED likelihood (bolometric.py:154-164: spectrum_mcmc's inner log_posterior) --------- */
+/* For every epoch e, observations ep_off[e] .. ep_off[e+1]-1 (filter index, luminosity density y, uncertainty dy);
+ * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged
+ * blackbody [f.synthesize(planck_fast, T, R) for f in filters].  precision 0 = float64, 1 = float32 arithmetic. */
+typedef struct lcf_sed lcf_sed;
+lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const double* tab_a, const double* tab_w,
+                          int32_t device, lcf_sed** out);
+void lcf_sed_destroy(lcf_sed* s);
+lcf_status lcf_sed_set_observations(lcf_sed* s, int64_t n_epochs, const int32_t* ep_off, const int32_t* filt_idx,
+                                    const double* y, const double* dy);
+/* cand[n_epochs][n_cand][n_par] (n_par = 2 or 3), out[n_epochs][n_cand]; kernel_ms (optional) receives the device
+ * time of the kernel alone (HIP events on the engine's stream). */
+lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int32_t sigma_type, const double* cand,
+                                  int32_t precision, double* out, double* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

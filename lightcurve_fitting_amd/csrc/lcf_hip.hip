@@ -20,6 +20,7 @@
 
 #include "lcf.h"
 #include "lcf_device.h"
+#include "lcf_host.h"
 
 using namespace lcf;
 
@@ -419,32 +420,15 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
 // =================================================================================================================
 // host side
 // =================================================================================================================
-namespace {
-
+namespace lcf {
 thread_local std::string g_err;
-
 lcf_status fail(lcf_status st, const std::string& msg) {
     g_err = msg;
     return st;
 }
+}  // namespace lcf
 
-#define LCF_HIP(call)                                                                                      \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return fail(e_ == hipErrorOutOfMemory ? LCF_ERR_OUT_OF_MEMORY : LCF_ERR_HIP,                   \
-                        std::string(#call) + ": " + hipGetErrorString(e_));                                \
-    } while (0)
-
-template <class T>
-lcf_status upload(const std::vector<T>& h, T** d, std::vector<void*>& owned) {
-    *d = nullptr;
-    if (h.empty()) return LCF_OK;
-    LCF_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
-    owned.push_back(*d);
-    LCF_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-    return LCF_OK;
-}
+namespace {
 
 }  // namespace
 
@@ -571,7 +555,7 @@ extern "C" {
 
 int32_t lcf_abi_version(void) { return LCF_ABI_VERSION; }
 
-const char* lcf_last_error(void) { return g_err.c_str(); }
+const char* lcf_last_error(void) { return lcf::g_err.c_str(); }
 
 int32_t lcf_device_count(void) {
     int n = 0;

@@ -91,6 +91,10 @@ SIGNATURES = [
     ('lcf_sampler_accept', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
+    ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('lcf_sed_destroy', None, [C.c_void_p]),
+    ('lcf_sed_set_observations', C.c_int, [C.c_void_p, C.c_int64, _ip, _ip, _dp, _dp]),
+    ('lcf_sed_log_likelihood', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp]),
 ]
 
 
@@ -337,3 +341,42 @@ class NativeSampler:
 
     def last_run_ms(self):
         return float(self._lib.lcf_sampler_last_run_ms(self._h))
+
+
+class SedEngine:
+    """Per-epoch blackbody SED likelihood on the device (``lcf_sed_*``): band tables are fixed at creation,
+    observations are set per batch of epochs, candidates are evaluated per call."""
+
+    def __init__(self, tab_off, tab_a, tab_w, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        off, a, w = _i32(tab_off), _f64(tab_a), _f64(tab_w)
+        _check(self._lib.lcf_sed_create(len(off) - 1, _ptr(off, _ip), _ptr(a), _ptr(w), int(device), C.byref(self._h)))
+        self.n_epochs = 0
+        self.last_kernel_ms = 0.
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.lcf_sed_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_observations(self, ep_off, filt_idx, y, dy):
+        off, f, y, dy = _i32(ep_off), _i32(filt_idx), _f64(y), _f64(dy)
+        if not (len(f) == len(y) == len(dy) == off[-1]):
+            raise ValueError('filt_idx, y, dy must have ep_off[-1] entries')
+        _check(self._lib.lcf_sed_set_observations(self._h, len(off) - 1, _ptr(off, _ip), _ptr(f, _ip), _ptr(y), _ptr(dy)))
+        self.n_epochs = len(off) - 1
+
+    def log_likelihood(self, cand, sigma_type=SIGMA_RELATIVE, precision=0):
+        """``cand``: (n_epochs, n_cand, 2 or 3) -> (n_epochs, n_cand)."""
+        cand = _f64(cand)
+        if cand.ndim != 3 or cand.shape[0] != self.n_epochs or cand.shape[2] not in (2, 3):
+            raise ValueError(f'candidates must have shape ({self.n_epochs}, n_cand, 2|3), got {cand.shape}')
+        out = np.empty(cand.shape[:2])
+        ms = C.c_double()
+        _check(self._lib.lcf_sed_log_likelihood(self._h, cand.shape[1], cand.shape[2], int(sigma_type), _ptr(cand),
+                                                int(precision), _ptr(out), C.byref(ms)))
+        self.last_kernel_ms = ms.value
+        return out

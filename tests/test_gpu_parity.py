@@ -259,3 +259,32 @@ def test_edge_shapes_and_errors():
     ref = O.log_likelihood(('ShockCooling', O.ShockCoolingOracle(0.)), t, [O.band(n) for n in names], y[:300],
                            0.1 * y[:300], P.T)
     assert relerr(m.log_likelihood(lc, P), ref) < TOL
+
+
+def test_config1_example_light_curve_end_to_end():
+    """BASELINE configs[0]: the reference's tutorial fit on the included SN 2016bkv photometry
+    (docs/source/usage.rst:174-200), from magnitudes to log-likelihoods, against the reference's own numbers."""
+    from lightcurve_fitting_amd.fitting import lightcurve_mcmc
+    from lightcurve_fitting_amd.lightcurve import LC
+    g = golden('config1')
+    lc = LC({'MJD': g['cfg1/MJD'], 'mag': g['cfg1/mag'], 'dmag': g['cfg1/dmag'], 'filter': g['cfg1/filter'],
+             'nondet': g['cfg1/nondet'], 'source': g['cfg1/source']}, meta={'dm': 30.79, 'redshift': 0.002})
+    lc.calcAbsMag()
+    lc.calcLum()
+    early = lc.where(MJD_min=57468., MJD_max=57485.)
+    model = M.ShockCooling2(early)
+    assert model.z == 0.002
+    assert relerr(model.log_likelihood(early, g['cfg1/P1a']), g['cfg1/ll1a']) < TOL
+    sel = lc[g['cfg1/sel1b']]
+    m5 = M.ShockCooling(sel)
+    assert relerr(m5.log_likelihood(sel, g['cfg1/P1b']), g['cfg1/ll1b']) < TOL
+    # the documented fit, 64 walkers (configs[0]); finite chain inside the priors, better than the starting box
+    priors = [M.UniformPrior(0., 100.)] * 3 + [M.UniformPrior(57468., 57468.7)]
+    np.random.seed(1)
+    sampler = lightcurve_mcmc(early, model, priors=priors, p_lo=[20., 2., 20., 57468.5], p_up=[50., 5., 50., 57468.7],
+                              nwalkers=64, nsteps=100, nsteps_burnin=200)
+    assert sampler.flatchain.shape == (6400, 4) and np.all(np.isfinite(sampler.flatchain))
+    assert np.all(sampler.flatchain[:, 3] > 57468.) and np.all(sampler.flatchain[:, 3] < 57468.7)
+    assert np.median(sampler.flatlnprobability) > np.max(g['cfg1/ll1a'])
+    t_max = model.t_max(sampler.flatchain.mean(axis=0))
+    assert np.isfinite(t_max)

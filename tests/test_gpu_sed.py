@@ -1,0 +1,87 @@
+"""Per-epoch blackbody SED engine (BASELINE configs[3]; reference bolometric.py:154-164): float64 parity against the
+reference's numbers, float32 mode within its stated error, closed-form helpers."""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+from lightcurve_fitting_amd import bolometric as B
+from oracle import lcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _epochs(g):
+    off = g['sed/ep_off']
+    return [([str(n) for n in g['sed/names'][off[e]:off[e + 1]]], g['sed/y'][off[e]:off[e + 1]],
+             g['sed/dy'][off[e]:off[e + 1]]) for e in range(len(off) - 1)]
+
+
+def test_sed_float64_parity():
+    g = golden('sed')
+    like = B.SpectrumLikelihood(_epochs(g), z=float(g['sed/z']))
+    c = g['sed/cand']
+    assert relerr(like(c[:, :, :2]), g['sed/ll']) < 1e-11
+    assert relerr(like(c, 'relative'), g['sed/ll_rel']) < 1e-11
+    assert relerr(like(c, 'absolute'), g['sed/ll_abs']) < 1e-11
+    with pytest.raises(Exception, match='sigma_type'):
+        like(c, 'bogus')
+    with pytest.raises(ValueError, match='shape'):
+        like(c[:3])
+    # single-epoch convenience wrapper; T <= 0 gives a zero model (power() semantics)
+    fl, y, dy = _epochs(g)[0]
+    got = B.spectrum_log_likelihood(fl, y, dy, c[0, :, 0], c[0, :, 1], z=float(g['sed/z']))
+    assert relerr(got, g['sed/ll'][0]) < 1e-11
+    zero = B.spectrum_log_likelihood(fl, y, dy, [-1., 0.], [1., 1.])
+    expect = -0.5 * np.sum(np.log(2 * np.pi * dy ** 2) + (y / dy) ** 2)
+    assert relerr(zero, [expect, expect]) < 1e-14
+
+
+def test_sed_float32_mode_error_is_bounded():
+    """configs[3] asks for float32 arithmetic with a float64 reference for the error report."""
+    g = golden('sed')
+    like = B.SpectrumLikelihood(_epochs(g), z=float(g['sed/z']))
+    c = g['sed/cand']
+    f64 = like(c, 'relative')
+    f32 = like(c, 'relative', precision='f32')
+    # chi^2 amplifies a model error eps by ~2 chi (y/sigma) eps: relative to lnL the error stays ~1e-6, and within
+    # 100 of each epoch's best candidate (where sampling happens) it is < 0.02 absolute
+    assert relerr(f32, f64) < 3e-5
+    near = f64 > f64.max(axis=1, keepdims=True) - 100.
+    assert np.max(np.abs(f32 - f64)[near]) < 0.02
+    # the best candidate of every epoch is the same in both precisions
+    assert np.array_equal(np.argmax(f32, axis=1), np.argmax(f64, axis=1))
+
+
+def test_sed_grid_at_config4_width_against_oracle():
+    """128 (T, R) candidates per epoch, 6 filters (UBVgri): float64 vs the CPU oracle, float32 vs float64."""
+    rng = np.random.default_rng(8)
+    names = ['U', 'B', 'V', 'g', 'r', 'i']
+    bands = [O.band(n) for n in names]
+    n_ep, n_c = 40, 128
+    epochs, cand = [], np.empty((n_ep, n_c, 2))
+    for e in range(n_ep):
+        Tt, Rt = rng.uniform(5., 50.), 10 ** rng.uniform(-1., 2.)
+        ytrue = np.array([O.synthesize_blackbody(b, Tt, Rt, 0.) for b in bands])
+        epochs.append((names, ytrue * (1 + 0.03 * rng.standard_normal(6)), 0.03 * ytrue))
+        cand[e, :, 0] = rng.uniform(1., 100., n_c)             # default priors of calculate_bolometric
+        cand[e, :, 1] = 10 ** rng.uniform(-2., 3., n_c)
+    like = B.SpectrumLikelihood(epochs, z=0.)
+    got = like(cand)
+    m = ('Blackbody', type('Z', (), {'z': 0.})())
+    ref = np.array([O.log_likelihood(m, None, bands, y, dy, cand[e].T) for e, (_, y, dy) in enumerate(epochs)])
+    assert relerr(got, ref) < 1e-11
+    f32 = like(cand, precision='f32')
+    assert relerr(f32, got) < 1e-4
+    assert like.engine.last_kernel_ms > 0.
+
+
+def test_pseudo_and_stefan_boltzmann():
+    p = golden('primitives')
+    assert relerr(B.pseudo(10., 1., 0.), 1.9045964708399877e+33) < 1e-13      # KA-8
+    assert relerr(B.pseudo(10., 1., 0.), p['misc/pseudo_10_1_0']) < 1e-13
+    assert relerr(B.stefan_boltzmann(10., 1.), 3.448780921664817e+33) < 1e-14
+    assert B.sigma_sb == p['const/values'][6]
+    assert relerr(B.pseudo(np.array([10., 20.]), np.array([1., 2.]), 0.01),
+                  [O.pseudo(10., 1., 0.01), O.pseudo(20., 2., 0.01)]) < 1e-13
+    lum, dlum = B.stefan_boltzmann(10., 1., 0.5, 0.1, 0.01)
+    assert dlum > 0 and lum == B.stefan_boltzmann(10., 1.)

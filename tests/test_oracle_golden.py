@@ -228,3 +228,19 @@ def test_philox_known_answers_and_sampler_statistics():
     assert 0.3 < nacc.mean() / 1500 < 0.85
     z, j, lnu = O.stretch_draws(7, 3, 1, np.arange(1000), 500)
     assert z.min() >= 0.5 and z.max() <= 2.0 and j.min() >= 0 and j.max() < 500 and np.all(lnu < 0)
+
+
+def test_sed_likelihoods():
+    """Per-epoch blackbody SED log-likelihoods (bolometric.py:154-164) for (T, R[, sigma]) candidates."""
+    g = golden('sed')
+    z = float(g['sed/z'])
+    m = ('Blackbody', type('Z', (), {'z': z})())
+    off = g['sed/ep_off']
+    for e in range(len(off) - 1):
+        sl = slice(off[e], off[e + 1])
+        bands = [O.band(str(n)) for n in g['sed/names'][sl]]
+        c = g['sed/cand'][e]
+        args = (m, None, bands, g['sed/y'][sl], g['sed/dy'][sl])
+        assert relerr(O.log_likelihood(*args, c[:, :2].T), g['sed/ll'][e]) < TOL
+        assert relerr(O.log_likelihood(*args, c.T, True, 'relative'), g['sed/ll_rel'][e]) < TOL
+        assert relerr(O.log_likelihood(*args, c.T, True, 'absolute'), g['sed/ll_abs'][e]) < TOL

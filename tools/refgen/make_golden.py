@@ -328,6 +328,82 @@ def gen_config3(models, filters, Table, out, nwalkers=12):
     out['cfg3/ll'] = np.array([m.log_likelihood(lc, p) for p in P])
 
 
+def gen_config1(models, filters, lightcurve, Table, out, ref_root):
+    """BASELINE.json configs[0]: the included example light curve (SN 2016bkv), docs/source/usage.rst:174-200.
+    No Milky-Way extinction is applied (the Fitzpatrick-99 package is absent): stated deviation, SURVEY section 8d."""
+    path = os.path.join(ref_root, 'lightcurve_fitting', 'example', 'SN2016bkv.txt')
+    rows = [ln.split() for ln in open(path) if ln.strip() and set(ln.strip()) - set('- ')]
+    header, rows = rows[0], rows[1:]
+    col = {h: [r[i] for r in rows] for i, h in enumerate(header)}
+    mjd = np.array(col['MJD'], float)
+    mag = np.array(col['mag'], float)
+    dmag = np.array(col['dmag'], float)
+    nondet = np.array([v == 'True' for v in col['nondet']])
+    names = np.array(col['filter'])
+    out['cfg1/MJD'], out['cfg1/mag'], out['cfg1/dmag'] = mjd, mag, dmag
+    out['cfg1/filter'], out['cfg1/nondet'], out['cfg1/source'] = names, nondet, np.array(col['source'])
+    dm, z = 30.79, 0.002
+    fobj = [filters.filtdict[n] for n in names]
+    zp = np.array([f.m0 for f in fobj]) + 90.19
+    lum, dlum = lightcurve.mag2flux(mag - dm, dmag, zp, nondet, 3.)
+    out['cfg1/lum'], out['cfg1/dlum'] = lum, dlum
+    rng = np.random.default_rng(1)
+    # 1a: docs example verbatim -- ShockCooling2 on the early light curve
+    early = (mjd >= 57468.) & (mjd <= 57485.)
+    out['cfg1/early'] = early
+    lc = make_lc(Table, filters, mjd[early], names[early], lum[early], dlum[early], redshift=z)
+    m = models.ShockCooling2(lc)
+    assert m.z == z
+    P = rng.uniform([20., 2., 20., 57468.5], [50., 5., 50., 57468.7], (64, 4))
+    out['cfg1/P1a'] = P
+    out['cfg1/ll1a'] = np.array([m.log_likelihood(lc, p) for p in P])
+    # 1b: ShockCooling (5 parameters) on the first 200 rows (by MJD) among filters B, V, i
+    sel = np.nonzero(np.isin(names, ['B', 'V', 'i']))[0]
+    sel = sel[np.argsort(mjd[sel], kind='stable')][:200]
+    out['cfg1/sel1b'] = sel
+    lc = make_lc(Table, filters, mjd[sel], names[sel], lum[sel], dlum[sel], redshift=z)
+    m = models.ShockCooling(lc)
+    P = rng.uniform([0.5, 0.2, 1., 0.5, 57467.], [2., 2., 5., 4., 57468.6], (64, 5))
+    out['cfg1/P1b'] = P
+    out['cfg1/ll1b'] = np.array([m.log_likelihood(lc, p) for p in P])
+
+
+def gen_sed(models, filters, out):
+    """Per-epoch SED likelihoods as spectrum_mcmc's inner log_posterior computes them (bolometric.py:139-164):
+    the reference's own Filter.synthesize(planck_fast, T, R) per filter, then the Gaussian likelihood."""
+    rng = np.random.default_rng(6)
+    pool = ['U', 'B', 'V', 'g', 'r', 'i', 'UVW2', 'UVM2', 'UVW1', 'z']
+    z = 0.01
+    ep_off, names, ys, dys, cands, ll, ll_rel, ll_abs = [0], [], [], [], [], [], [], []
+    for e in range(12):
+        nf = rng.integers(2, 9)
+        fl = list(rng.choice(pool, nf, replace=False))
+        Tt, Rt = rng.uniform(5., 40.), 10 ** rng.uniform(-0.5, 1.)
+        fobj = [filters.filtdict[n] for n in fl]
+        ytrue = np.array([f.synthesize(models.planck_fast, Tt, Rt, z=z, ebv=0.) for f in fobj])
+        y = ytrue * (1 + 0.05 * rng.standard_normal(nf))
+        dy = 0.05 * ytrue * rng.uniform(0.5, 2., nf)
+        c = np.column_stack([Tt * rng.uniform(0.5, 2., 24), Rt * rng.uniform(0.5, 2., 24), rng.uniform(0., 3., 24)])
+        for (T, R, sg) in c:
+            y_fit = np.array([f.synthesize(models.planck_fast, T, R, z=z, ebv=0.) for f in fobj])
+            for sigma, dest in ((dy, ll), (np.sqrt(dy ** 2. + (sg * dy) ** 2.), ll_rel),
+                                (np.sqrt(dy ** 2. + (sg * np.median(dy)) ** 2.), ll_abs)):
+                dest.append(-0.5 * np.sum(np.log(2 * np.pi * sigma ** 2.) + ((y - y_fit) / sigma) ** 2.))
+        ep_off.append(ep_off[-1] + nf)
+        names += fl
+        ys += list(y)
+        dys += list(dy)
+        cands.append(c)
+    out['sed/z'] = np.array(z)
+    out['sed/ep_off'] = np.array(ep_off)
+    out['sed/names'] = np.array(names)
+    out['sed/y'], out['sed/dy'] = np.array(ys), np.array(dys)
+    out['sed/cand'] = np.array(cands)
+    out['sed/ll'] = np.array(ll).reshape(12, 24)
+    out['sed/ll_rel'] = np.array(ll_rel).reshape(12, 24)
+    out['sed/ll_abs'] = np.array(ll_abs).reshape(12, 24)
+
+
 def gen_priors_misc(models, filters, bolometric, lightcurve, out):
     u = models.UniformPrior(0., 1.)
     lu = models.LogUniformPrior(0.01, 1000.)
@@ -357,6 +433,7 @@ def gen_priors_misc(models, filters, bolometric, lightcurve, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--only', default='', help='comma-separated subset of fixture files to regenerate')
     args = ap.parse_args()
     models, filters, bolometric, lightcurve, Table = import_reference(args.ref)
     os.makedirs(GOLD, exist_ok=True)
@@ -368,8 +445,13 @@ def main():
         'companion': lambda o: gen_companion(models, filters, Table, o),
         'config2': lambda o: gen_config2(models, filters, Table, o),
         'config3': lambda o: gen_config3(models, filters, Table, o),
+        'config1': lambda o: gen_config1(models, filters, lightcurve, Table, o, args.ref),
+        'sed': lambda o: gen_sed(models, filters, o),
     }
+    only = set(args.only.split(',')) if args.only else None
     for name, job in jobs.items():
+        if only and name not in only:
+            continue
         out = {}
         job(out)
         path = os.path.join(GOLD, name + '.npz')
