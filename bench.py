@@ -132,9 +132,72 @@ def run_sed(args):
         'f32_vs_f64_lnL_relative_error': {'max': float(err.max()), 'median': float(np.median(err))}}), flush=True)
 
 
+def run_population(args):
+    """BASELINE configs[4]: population mode -- independent synthetic transients (config-2-like, 100 epochs x 6 filters
+    = 600 points, own truth drawn +-20 %), 512 walkers each, transients partitioned over the GPUs (no communication).
+    32 transients per GPU.  Extra workload: prints its own JSON line."""
+    import torch
+    from lightcurve_fitting_amd import models as M
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    n_tr, nw = 32 * world, 512
+    rng = np.random.default_rng(SEED + 5)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    problems, x0 = [], {}
+    for k in range(n_tr):
+        truth = TRUTH * rng.uniform(0.8, 1.2, 5)
+        epochs = np.sort(rng.uniform(0.5, 10., 100))
+        t, names = np.repeat(epochs, 6), list(np.tile(BANDS, 100))
+        model = M.ShockCooling(redshift=0.)
+        model.device = local_rank
+        noise = rng.standard_normal(600)
+        walkers = truth * rng.uniform(0.9, 1.1, (nw, 5))
+        if k * world // n_tr == rank:  # only this rank's share is built on the device
+            ytrue = model(t, names, *truth)
+            problems.append((model, {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * noise), 'dlum': 0.05 * ytrue},
+                             priors))
+        else:
+            problems.append((model, None, priors))
+        x0[k] = walkers
+    pop = PopulationSampler(problems, nw, seed=SEED, device=local_rank)
+    pop.run_mcmc(x0, args.warmup, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    pop.run_mcmc(None, args.steps, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'walker-steps/sec (population of independent ensembles)',
+                          'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                          'data': 'synthetic',
+                          'config': {'workload': 'BASELINE configs[4]: population mode, 32 transients per GPU x 512 '
+                                                 'walkers, 600 points each (100 epochs x UBVgri)',
+                                     'transients': n_tr, 'walkers_per_transient': nw, 'points': 600}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed'],
+    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population'],
                     help="'mcmc' (default) = the headline configs[1] line; 'sed' = configs[3] extra line")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -146,6 +209,8 @@ def main():
     if args.workload == 'sed':
         import torch  # noqa: F401  (one HIP runtime per process: see engine.load_library)
         return run_sed(args)
+    if args.workload == 'population':
+        return run_population(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -157,6 +157,11 @@ enum { LCF_SPLIT_IDENTITY = 0, LCF_SPLIT_RANDOM = 1, LCF_SPLIT_HOST = 2 };
 /* Run n_steps ensemble steps numbered from first_step (the step number is an RNG counter word). */
 lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                            const int32_t* perm, int32_t store_chain);
+/* The same split in two: enqueue the whole run on the engine's stream and return at once / wait for it and check.
+ * Samplers on different engines (population mode: one transient each) run concurrently between the two calls. */
+lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 const int32_t* perm, int32_t store_chain);
+lcf_status lcf_sampler_wait(lcf_sampler* s);
 /* Chain of the last run: chain[n_steps][n_walkers][n_dim], log_prob[n_steps][n_walkers] (either may be NULL). */
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob);
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);

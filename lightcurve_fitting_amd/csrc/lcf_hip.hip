@@ -1151,8 +1151,10 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     return LCF_OK;
 }
 
-lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
-                           const int32_t* perm, int32_t store_chain) {
+// Enqueue a whole run on the engine's stream and return: several samplers (one engine each = one transient of a
+// population) then execute concurrently on the device.  lcf_sampler_wait() completes it.
+lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 const int32_t* perm, int32_t store_chain) {
     if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     hipStream_t st = s->e->stream;
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
@@ -1164,11 +1166,22 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
     }
     if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
-    LCF_HIP(hipStreamSynchronize(st));
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_wait(lcf_sampler* s) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    LCF_HIP(hipSetDevice(s->e->device));
+    LCF_HIP(hipStreamSynchronize(s->e->stream));
     float ms = 0.f;
-    LCF_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    s->last_ms = ms;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = ms;
     return lcf_sampler_check(s);
+}
+
+lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                           const int32_t* perm, int32_t store_chain) {
+    if (lcf_status st = lcf_sampler_run_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
+    return lcf_sampler_wait(s);
 }
 
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob) {

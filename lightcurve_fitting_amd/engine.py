@@ -82,6 +82,8 @@ SIGNATURES = [
     ('lcf_sampler_set_state', C.c_int, [C.c_void_p, _dp]),
     ('lcf_sampler_get_state', C.c_int, [C.c_void_p, _dp, _dp]),
     ('lcf_sampler_run', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_run_async', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_wait', C.c_int, [C.c_void_p]),
     ('lcf_sampler_get_chain', C.c_int, [C.c_void_p, _dp, _dp]),
     ('lcf_sampler_get_naccepted', C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ('lcf_sampler_last_run_ms', C.c_double, [C.c_void_p]),
@@ -306,6 +308,15 @@ class NativeSampler:
         mode, keep, pp = self._split(split, nsteps, self.nwalkers)
         _check(self._lib.lcf_sampler_run(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
         self._last = (int(nsteps), bool(store))
+
+    def run_async(self, first_step, nsteps, split='random', store=True):
+        """Enqueue the run and return; :meth:`wait` completes it (population mode: many samplers in flight)."""
+        mode, keep, pp = self._split(split, nsteps, self.nwalkers)
+        _check(self._lib.lcf_sampler_run_async(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
+        self._last = (int(nsteps), bool(store))
+
+    def wait(self):
+        _check(self._lib.lcf_sampler_wait(self._h))
 
     def begin(self, first_step, nsteps, split='random', store=True):
         mode, keep, pp = self._split(split, nsteps, self.nwalkers)

@@ -132,6 +132,55 @@ class ShardedStretchDriver:
         b.finish()
 
 
+def partition(n_items, world_size, rank):
+    """Indices of the items (transients, epochs) owned by ``rank``: contiguous, balanced blocks."""
+    lo, hi, _ = shard_bounds(n_items, world_size, rank)
+    return range(lo, hi)
+
+
+class PopulationSampler:
+    """Population mode (BASELINE configs[4]): many independent transients, each with its own light curve, engine and
+    walker ensemble.  Embarrassingly parallel: transients are partitioned over the ranks of a process group (no
+    communication) and, on each GPU, all of a rank's ensembles are enqueued on their own HIP streams before any is
+    waited for, so that small per-transient kernels overlap on the device.
+
+    ``problems``: sequence of ``(model, lc, priors)``; every rank passes the full list and keeps
+    ``self.indices`` (its share).  ``seed + index`` keys each transient's RNG, so results do not depend on the
+    number of GPUs."""
+
+    def __init__(self, problems, nwalkers, seed=0, a=2.0, group=None, device=None):
+        world, rank = 1, 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world, rank = dist.get_world_size(group), dist.get_rank(group)
+        except ImportError:
+            pass
+        self.indices = list(partition(len(problems), world, rank))
+        self.samplers = {}
+        for k in self.indices:
+            model, lc, priors = problems[k]
+            if device is not None:
+                model.device = device
+            eng = model.engine_for(lc, priors=priors)
+            self.samplers[k] = EnsembleSampler(nwalkers, eng.ndim, eng, seed=seed + k, a=a)
+        self.nwalkers = nwalkers
+
+    def run_mcmc(self, initial_states, nsteps, store=True):
+        """``initial_states``: mapping/sequence index -> (nwalkers, ndim) coordinates, or None to continue."""
+        started = []
+        for k, s in self.samplers.items():
+            x0 = None if initial_states is None else initial_states[k]
+            s._start(x0, nsteps, store)
+            started.append(s)
+        for s in started:
+            s._finish(nsteps, store)
+        return {k: s._state for k, s in self.samplers.items()}
+
+    def __getitem__(self, k):
+        return self.samplers[k]
+
+
 class EnsembleSampler:
     """Drop-in for the subset of ``emcee.EnsembleSampler`` the reference uses, bound to one engine.
 
@@ -184,8 +233,7 @@ class EnsembleSampler:
         self._lp = np.empty((0, self.nwalkers))
         self._naccepted[:] = 0
 
-    def run_mcmc(self, initial_state, nsteps, progress=False, progress_kwargs=None, skip_initial_state_check=False,
-                 store=True, **kwargs):
+    def _start(self, initial_state, nsteps, store=True, skip_initial_state_check=False, asynchronous=True):
         if initial_state is not None:
             coords = np.array(initial_state[0] if isinstance(initial_state, tuple) else initial_state,
                               dtype=np.float64)
@@ -207,16 +255,31 @@ class EnsembleSampler:
         split = 'random' if self.randomize_split else 'identity'
         if self.randomize_split and self.nwalkers > 16384:  # beyond the device sort: host-generated colouring
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
+        self._in_flight = False
         try:
             if self._distributed():
                 ShardedStretchDriver(NativeBackend(self._native), self._group,
                                      force_collective=self._force_sharded).run(self._steps_done, nsteps, split, store)
+            elif asynchronous:
+                self._native.run_async(self._steps_done, nsteps, split, store)
+                self._in_flight = True
             else:
                 self._native.run(self._steps_done, nsteps, split, store)
         except Exception as exc:
             if getattr(exc, 'status', None) == 6:
                 raise ValueError('Probability function returned NaN') from None
             raise
+
+    def _finish(self, nsteps, store=True):
+        try:
+            if self._in_flight:
+                self._native.wait()
+        except Exception as exc:
+            if getattr(exc, 'status', None) == 6:
+                raise ValueError('Probability function returned NaN') from None
+            raise
+        finally:
+            self._in_flight = False
         self._steps_done += nsteps
         if store and nsteps:
             chain, lp = self._native.get_chain()
@@ -226,6 +289,11 @@ class EnsembleSampler:
         x, lp = self._native.get_state()
         self._state = State(x, lp, None)
         return self._state
+
+    def run_mcmc(self, initial_state, nsteps, progress=False, progress_kwargs=None, skip_initial_state_check=False,
+                 store=True, **kwargs):
+        self._start(initial_state, nsteps, store, skip_initial_state_check, asynchronous=False)
+        return self._finish(nsteps, store)
 
     def get_chain(self, flat=False, thin=1, discard=0):
         c = self._chain[discard::thin]

@@ -155,3 +155,27 @@ def test_collective_path_single_rank_nccl():
     b.run_mcmc(x0, 8)
     assert np.array_equal(a.get_chain(), b.get_chain())
     assert np.array_equal(a.get_log_prob(), b.get_log_prob())
+
+
+def test_population_mode_equals_individual_runs():
+    """BASELINE configs[4] shape in small: independent transients, all ensembles in flight at once on their own
+    streams; every chain equals the chain of that transient run alone (bitwise)."""
+    from lightcurve_fitting_amd.sampler import PopulationSampler, partition
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    problems, x0 = [], {}
+    for k in range(5):
+        pb = small_problem(npts=40 + 7 * k, seed=20 + k)
+        lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
+        problems.append((M.ShockCooling(redshift=0.), lc, priors))
+        x0[k] = pb['truth'] * (1 + 0.05 * np.random.default_rng(k).standard_normal((32, 5)))
+    pop = PopulationSampler(problems, 32, seed=100)
+    assert pop.indices == [0, 1, 2, 3, 4]
+    pop.run_mcmc(x0, 10)
+    pop.run_mcmc(None, 5)
+    for k, (model, lc, pri) in enumerate(problems):
+        solo = EnsembleSampler(32, 5, M.ShockCooling(redshift=0.).engine_for(lc, priors=pri), seed=100 + k)
+        solo.run_mcmc(x0[k], 10)
+        solo.run_mcmc(None, 5)
+        assert np.array_equal(pop[k].get_chain(), solo.get_chain())
+        assert pop[k].chain.shape == (32, 15, 5)
+    assert [list(partition(7, 3, r)) for r in range(3)] == [[0, 1, 2], [3, 4, 5], [6]]
