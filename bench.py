@@ -224,6 +224,12 @@ def main():
     else:
         torch.cuda.set_device(0)
         local_rank = 0
+    force_sharded = world == 1 and os.environ.get('LCF_BENCH_FORCE_SHARDED') == '1'
+    if force_sharded:  # diagnostic: exercise the multi-GPU code path (RCCL all-gather included) with one rank
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     n_gpus = world
 
     from lightcurve_fitting_amd.sampler import EnsembleSampler
@@ -231,7 +237,7 @@ def main():
     engine = model.engine_for(lc, priors=priors)
     engine.set_variant(args.variant)
     n_walkers = WALKERS_PER_GPU * n_gpus
-    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED)
+    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED, force_sharded=force_sharded)
     x0 = initial_walkers(n_walkers)
 
     def barrier():
@@ -269,7 +275,8 @@ def main():
                                    '500 synthetic epochs x 6 filters (UBVgri) = 3000 points, float64, '
                                    'device-resident stretch-move ensemble',
                        'walkers': n_walkers, 'points': ALG_POINTS, 'planck_samples_per_eval': ALG_SAMPLES,
-                       'parallelism': f'walker-sharded x{n_gpus}' if n_gpus > 1 else 'single GPU'},
+                       'parallelism': f'walker-sharded x{n_gpus}' if n_gpus > 1 else
+                       ('single GPU, multi-GPU code path forced' if force_sharded else 'single GPU')},
             'roofline': {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR,
                          'unit': 'Tinstr/s', 'frac': achieved / PEAK_FP64_TINSTR,
                          'note': 'FP64 vector-ALU lane-instructions: algorithmic 34 per Planck sample + 68 per point '

@@ -178,6 +178,8 @@ lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps
 lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void* stream);
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream);
 lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* stream);
+/* Phases 1 + 2 in one call (fewer launches: the thermal states of the shard ride on the proposal kernel). */
+lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi, void* stream);
 /* Device pointer to newlp[n_walkers/2] (float64) for the collective. */
 void* lcf_sampler_newlp_ptr(lcf_sampler* s);
 lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGPROB if a NaN was seen */

@@ -1123,6 +1123,20 @@ lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void*
     s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
     return launch_next(s, true, false, 0, 0, stream ? (hipStream_t)stream : s->e->stream);
 }
+// propose + evaluate in one call: the shard is known, so the thermal states of [lo, hi) are computed by the same
+// launch that draws the proposals (3 launches per half-step and rank: k_step, k_points, k_finalize).
+lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi, void* stream) {
+    if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
+    if (lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
+    const long long g = s->g_run0 + 2 * (step - s->run_first) + half;
+    if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
+    hipStream_t st = stream ? (hipStream_t)stream : s->e->stream;
+    s->ds.inline_finalize = 0;
+    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
+    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st);
+}
+
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
     if (!s || lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
     if (!s->pending) return fail(LCF_ERR_STATE, "lcf_sampler_propose must precede lcf_sampler_evaluate");

@@ -91,6 +91,7 @@ SIGNATURES = [
     ('lcf_sampler_propose', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     ('lcf_sampler_evaluate', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_accept', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
     ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -331,6 +332,9 @@ class NativeSampler:
 
     def accept(self, step, half, stream=0):
         _check(self._lib.lcf_sampler_accept(self._h, int(step), int(half), C.c_void_p(stream)))
+
+    def half_step(self, step, half, lo, hi, stream=0):
+        _check(self._lib.lcf_sampler_half_step(self._h, int(step), int(half), int(lo), int(hi), C.c_void_p(stream)))
 
     def newlp_ptr(self):
         return self._lib.lcf_sampler_newlp_ptr(self._h)

@@ -48,19 +48,25 @@ class NativeBackend:
         self.ns = native_sampler
         self.n_half = native_sampler.nwalkers // 2
         self._newlp = {}
+        self._stream = None
 
     def begin(self, first_step, nsteps, split, store):
         self.ns.begin(first_step, nsteps, split, store)
 
     def stream(self):
-        import torch
-        return torch.cuda.current_stream().cuda_stream
+        if self._stream is None:
+            import torch
+            self._stream = torch.cuda.current_stream().cuda_stream
+        return self._stream
 
     def propose(self, step, half):
         self.ns.propose(step, half, self.stream())
 
     def evaluate(self, lo, hi):
         self.ns.evaluate(lo, hi, self.stream())
+
+    def half_step(self, step, half, lo, hi):
+        self.ns.half_step(step, half, lo, hi, self.stream())
 
     def accept(self, step, half):
         self.ns.accept(step, half, self.stream())
@@ -113,8 +119,11 @@ class ShardedStretchDriver:
         for k in range(nsteps):
             step = first_step + k
             for half in (0, 1):
-                b.propose(step, half)
-                b.evaluate(self.lo, self.hi)
+                if hasattr(b, 'half_step'):
+                    b.half_step(step, half, self.lo, self.hi)
+                else:
+                    b.propose(step, half)
+                    b.evaluate(self.lo, self.hi)
                 if self.collective and self.in_place:
                     newlp = b.newlp()
                     self.dist.all_gather_into_tensor(newlp, newlp[self.lo:self.hi], group=self.group)
