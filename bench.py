@@ -203,7 +203,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--variant', type=int, default=1, help='band-sum variant: 1 fused (default), 0 libm')
+    ap.add_argument('--variant', type=int, default=2,
+                    help='band sum: 2 = fused + Gauss-compressed tables (default), 1 = fused over the full tables, 0 = libm')
     args = ap.parse_args()
 
     if args.workload == 'sed':

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 1
+#define LCF_ABI_VERSION 2
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -92,6 +92,13 @@ typedef struct lcf_problem {
     const int32_t* tab_off;   /* [n_filters + 1] */
     const double* tab_a;      /* [tab_off[n_filters]] */
     const double* tab_w;      /* [tab_off[n_filters]] */
+    /* Optional compressed companions (all NULL = none): per filter a shorter table (the Gauss quadrature of the full
+     * table's own discrete measure, computed by the host packer) that reproduces the band sum to 2e-14 for every
+     * temperature T >= ctab_tmin[i]; the engine switches per data point and uses the full table below it. */
+    const int32_t* ctab_off;  /* [n_filters + 1] */
+    const double* ctab_a;     /* [ctab_off[n_filters]] */
+    const double* ctab_w;     /* [ctab_off[n_filters]] */
+    const double* ctab_tmin;  /* [n_filters] kK; +inf = never use the compressed table of this filter */
     const int32_t* filt_kasen_par; /* [n_filters] or NULL */
     const int32_t* filt_sifto_par; /* [n_filters] or NULL */
     const int32_t* filt_dt_par;    /* [n_filters] or NULL */
@@ -118,9 +125,10 @@ lcf_status lcf_engine_create(const lcf_problem* problem, int32_t device, lcf_eng
 void lcf_engine_destroy(lcf_engine* e);
 int32_t lcf_engine_ndim(const lcf_engine* e);
 int64_t lcf_engine_npoints(const lcf_engine* e);
-/* Planck samples one log-likelihood evaluation sums (after dropping nothing): sum over points of K_filter. */
+/* Planck samples of one log-likelihood evaluation over the full tables: sum over points of K_filter. */
 int64_t lcf_engine_samples_per_eval(const lcf_engine* e);
-/* Select the band-sum variant: 0 = libm expm1 + divide (reference-shaped), 1 = fused fast path (default). */
+/* Select the band-sum variant: 0 = libm expm1 + divide over the full tables (reference-shaped), 1 = fused fast path
+ * over the full tables, 2 = fused fast path over the compressed tables where valid (default when they are given). */
 lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant);
 
 /* Model.log_likelihood (models.py:93-136) for a block of n walkers.  Host pointers. out[n]. */

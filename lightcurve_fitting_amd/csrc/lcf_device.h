@@ -43,7 +43,7 @@ struct DevProblem {
     int model, n_points, n_chunks, n_filters;
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
-    int n_epochs, use_therm, pad0, pad1;
+    int n_epochs, use_therm, use_ctab, pad1;
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double sigma_unit_abs;  // median(dy)
@@ -53,6 +53,9 @@ struct DevProblem {
     const double* dy;
     const int* pt_off;   // first table sample of the point's filter
     const int* pt_cnt;   // number of table samples
+    const int* pt_coff;  // compressed table of the point's filter: first sample, count, validity threshold [kK]
+    const int* pt_ccnt;
+    const double* pt_tmin;
     const int* pt_filt;  // filter index
     const int* pt_orig;  // index in the caller's order
     const int* pt_epoch; // index into epoch_t (distinct observation times)

@@ -53,21 +53,37 @@ struct PointOut {
     double pref;
 };
 
-// Everything one lane does for its data point: thermal state -> band sum(s) -> template term.
+// The two tables of a point's filter (offsets relative to `base`): the full one and its Gauss-compressed companion,
+// valid for T >= tmin.
+template <class TabPtr>
+struct TabSel {
+    TabPtr base;
+    int off, cnt, coff, ccnt;
+    double tmin;
+};
+
+template <int VARIANT, class TabPtr>
+__device__ inline double band_sum_at(const TabSel<TabPtr>& ts, bool use_ctab, double T, const ExpTab et) {
+    const bool c = use_ctab && T >= ts.tmin;
+    const TabPtr tab = ts.base + (c ? ts.coff : ts.off);
+    const int cnt = c ? ts.ccnt : ts.cnt;
+    const double invT = 1. / T;
+    return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
+}
+
+// Everything one lane does for its data point after the thermal state: band sum(s) -> template term.
 template <int VARIANT, class TabPtr>
 __device__ inline PointOut point_model(const DevProblem& pb, const double* __restrict__ c,
-                                       const double* __restrict__ p, double t_in, int filt, TabPtr tab, int cnt,
+                                       const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
                                        const ExpTab et, double T, double pref) {
     PointOut o;
     o.T = T;
     o.pref = pref;
     double S = 0.;
     if (o.T > 0.) {
-        const double invT = 1. / o.T;
-        S = VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
+        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, o.T, et);
         if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
-            const double invT2 = invT * (1. / 0.74);
-            const double S2 = VARIANT == 0 ? band_sum_ref(tab, cnt, invT2) : band_sum_fast(tab, cnt, invT2, et);
+            const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 0.74 * o.T, et);
             S = fmin(S, S2 * (1. / (0.74 * 0.74 * 0.74 * 0.74)));
         }
     }
@@ -137,7 +153,6 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
     if (i < pb.n_points) {
         const double t_in = pb.t[i];
         const int filt = pb.pt_filt[i];
-        const int off = pb.pt_off[i], cnt = pb.pt_cnt[i];
         PointOut o;
         double T, pref;
         if (THERM) {
@@ -147,11 +162,9 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
         } else {
             thermal_state(pb, c, t_in, T, pref);
         }
-        if (LDS_TAB) {
-            o = point_model<VARIANT>(pb, c, p, t_in, filt, (const double2*)(ltab + (off - tlo)), cnt, et, T, pref);
-        } else {
-            o = point_model<VARIANT>(pb, c, p, t_in, filt, pb.tab + off, cnt, et, T, pref);
-        }
+        const TabSel<const double2*> ts{LDS_TAB ? (const double2*)ltab - tlo : pb.tab, pb.pt_off[i], pb.pt_cnt[i],
+                                        pb.pt_coff[i], pb.pt_ccnt[i], pb.pt_tmin[i]};
+        o = point_model<VARIANT>(pb, c, p, t_in, filt, ts, et, T, pref);
         if (MODE == 0) {  // models.py:121-135
             const double dy = pb.dy[i];
             const double r = pb.y[i] - o.yfit;
@@ -199,6 +212,8 @@ __global__ void k_finalize(const DevProblem pb, int n, const double* __restrict_
 template <int VARIANT>
 __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, int m, const int* __restrict__ filt,
                                                          const int* __restrict__ tab_off,
+                                                         const int* __restrict__ ctab_off,
+                                                         const double* __restrict__ ctmin,
                                                          const double* __restrict__ T, const double* __restrict__ R,
                                                          double* __restrict__ out) {
     __shared__ double exptab[kExpTabSize];
@@ -207,12 +222,13 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const int f = filt[i];
-    const int off = tab_off[f], cnt = tab_off[f + 1] - off;
     const double Tk = T[i], r = R[i];
     double S = 0.;
     if (Tk > 0. && Tk < kTmax) {
         const ExpTab et{exptab};
-        S = VARIANT == 0 ? band_sum_ref(pb.tab + off, cnt, 1. / Tk) : band_sum_fast(pb.tab + off, cnt, 1. / Tk, et);
+        const TabSel<const double2*> ts{pb.tab, tab_off[2 * f], tab_off[2 * f + 1], ctab_off[2 * f],
+                                        ctab_off[2 * f + 1], ctmin[f]};
+        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, Tk, et);
     }
     out[i] = r * r * S;
 }
@@ -439,7 +455,10 @@ struct lcf_engine {
     hipStream_t stream = nullptr;
     int64_t samples_per_eval = 0;
     size_t lds_bytes = 0;
-    int* d_tab_off = nullptr;
+    int* d_tab_off = nullptr;   // per filter: (offset, count) of the full table in the device table
+    int* d_ctab_off = nullptr;  // per filter: (offset, count) of the compressed table
+    double* d_ctmin = nullptr;
+    bool have_ctab = false;
     // workspace for n walkers
     int64_t cap = 0;
     double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
@@ -626,22 +645,40 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<int> hoff(N), hcnt(N), hfilt(N), horig(N);
     double lognorm = 0.;
     int64_t samples = 0;
-    // device tables: every filter padded to a multiple of four samples with zero weights (exactly 0 contribution)
-    std::vector<int> poff(NF + 1, 0);
-    std::vector<double2> htab;
-    for (int f = 0; f < NF; ++f) {
-        const int k0 = pr->tab_off[f], k1 = pr->tab_off[f + 1];
-        for (int k = k0; k < k1; ++k) {
-            if (!(pr->tab_a[k] > 0.) || !std::isfinite(pr->tab_a[k]) || !std::isfinite(pr->tab_w[k])) {
-                delete e;
-                return fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0 and finite W_k");
-            }
-            htab.push_back(make_double2(pr->tab_a[k], pr->tab_w[k]));
-        }
-        const double apad = k1 > k0 ? pr->tab_a[k1 - 1] : 1.;
-        while ((htab.size() - poff[f]) % 4) htab.push_back(make_double2(apad, 0.));
-        poff[f + 1] = (int)htab.size();
+    // device table: per filter [full | compressed], each padded to a multiple of four samples with zero weights
+    // (exactly 0 contribution)
+    const bool have_ctab = pr->ctab_off && pr->ctab_a && pr->ctab_w && pr->ctab_tmin;
+    if (have_ctab) {
+        if (pr->ctab_off[0] != 0) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off[0] must be 0"));
+        for (int f = 0; f < NF; ++f)
+            if (pr->ctab_off[f + 1] < pr->ctab_off[f])
+                return bail(fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off must be non-decreasing"));
     }
+    std::vector<int> pfull(2 * NF, 0), pcomp(2 * NF, 0);  // (offset, count) pairs
+    std::vector<double> ptmin(NF, INFINITY);
+    std::vector<double2> htab;
+    auto append = [&](const double* a, const double* w, int k0, int k1, int* slot) -> bool {
+        slot[0] = (int)htab.size();
+        for (int k = k0; k < k1; ++k) {
+            if (!(a[k] > 0.) || !std::isfinite(a[k]) || !std::isfinite(w[k])) return false;
+            htab.push_back(make_double2(a[k], w[k]));
+        }
+        const double apad = k1 > k0 ? a[k1 - 1] : 1.;
+        while ((htab.size() - slot[0]) % 4) htab.push_back(make_double2(apad, 0.));
+        slot[1] = (int)htab.size() - slot[0];
+        return true;
+    };
+    for (int f = 0; f < NF; ++f) {
+        bool ok = append(pr->tab_a, pr->tab_w, pr->tab_off[f], pr->tab_off[f + 1], &pfull[2 * f]);
+        if (ok && have_ctab && pr->ctab_off[f + 1] > pr->ctab_off[f]) {
+            ok = append(pr->ctab_a, pr->ctab_w, pr->ctab_off[f], pr->ctab_off[f + 1], &pcomp[2 * f]);
+            ptmin[f] = pr->ctab_tmin[f];
+            if (!(ptmin[f] >= 0.)) ok = false;
+        }
+        if (!ok) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0, finite W_k, t_min >= 0"));
+    }
+    std::vector<int> hcoff(N), hccnt(N);
+    std::vector<double> htmin(N);
     for (int i = 0; i < N; ++i) {
         const int o = order[i], f = pr->filt_idx[o];
         ht[i] = pr->t[o];
@@ -649,8 +686,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         hdy[i] = pr->dy[o];
         hfilt[i] = f;
         horig[i] = o;
-        hoff[i] = poff[f];
-        hcnt[i] = poff[f + 1] - poff[f];
+        hoff[i] = pfull[2 * f];
+        hcnt[i] = pfull[2 * f + 1];
+        hcoff[i] = pcomp[2 * f];
+        hccnt[i] = pcomp[2 * f + 1];
+        htmin[i] = pcomp[2 * f + 1] > 0 ? ptmin[f] : INFINITY;
         samples += pr->tab_off[f + 1] - pr->tab_off[f];
     }
     for (int i = 0; i < N; ++i) lognorm += std::log(2. * M_PI * pr->dy[i] * pr->dy[i]);  // caller order, like np.sum
@@ -678,17 +718,21 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         for (int i = a; i < b; ++i) {
             lo = std::min(lo, hoff[i]);
             hi = std::max(hi, hoff[i] + hcnt[i]);
+            if (hccnt[i] > 0) {
+                lo = std::min(lo, hcoff[i]);
+                hi = std::max(hi, hcoff[i] + hccnt[i]);
+            }
         }
         clo[c] = lo;
         cn[c] = hi - lo;
         max_cn = std::max(max_cn, cn[c]);
     }
-    std::vector<int> htaboff(poff);
+    std::vector<int> htaboff(pfull);
     if (htab.empty()) htab.push_back(make_double2(1., 0.));
     std::vector<int> corder(n_chunks);
     std::iota(corder.begin(), corder.end(), 0);
     std::vector<long long> ccost(n_chunks, 0);
-    for (int i = 0; i < N; ++i) ccost[i / kBlock] += hcnt[i] + 12;  // samples + per-point overhead
+    for (int i = 0; i < N; ++i) ccost[i / kBlock] += (hccnt[i] > 0 ? hccnt[i] : hcnt[i]) + 12;  // samples + overhead
     std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return ccost[a] > ccost[b]; });
     std::vector<double> hexp(kExpTabSize);
     for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
@@ -708,6 +752,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_epochs = (int)epochs.size();
     dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
     dp.variant = 1;
+    dp.use_ctab = have_ctab ? 1 : 0;
+    e->have_ctab = have_ctab;
     std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
@@ -721,9 +767,13 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
     UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hoff, doff); UP(hcnt, dcnt); UP(hfilt, dfilt); UP(horig, dorig);
     UP(clo, dclo); UP(cn, dcn); UP(htab, dtab); UP(htaboff, e->d_tab_off);
-    int *dcord, *depoch;
-    double *dexp, *depocht;
+    int *dcord, *depoch, *dcoff, *dccnt;
+    double *dexp, *depocht, *dtmin;
     UP(corder, dcord); UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
+    UP(hcoff, dcoff); UP(hccnt, dccnt); UP(htmin, dtmin); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
+    dp.pt_coff = dcoff;
+    dp.pt_ccnt = dccnt;
+    dp.pt_tmin = dtmin;
     dp.pt_epoch = depoch;
     dp.epoch_t = depocht;
     dp.chunk_order = dcord;
@@ -760,8 +810,10 @@ int64_t lcf_engine_npoints(const lcf_engine* e) { return e ? e->dp.n_points : 0;
 int64_t lcf_engine_samples_per_eval(const lcf_engine* e) { return e ? e->samples_per_eval : 0; }
 
 lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant) {
-    if (!e || variant < 0 || variant > 1) return fail(LCF_ERR_INVALID_ARGUMENT, "variant must be 0 or 1");
-    e->dp.variant = variant;
+    if (!e || variant < 0 || variant > 2) return fail(LCF_ERR_INVALID_ARGUMENT, "variant must be 0, 1 or 2");
+    if (variant == 2 && !e->have_ctab) return fail(LCF_ERR_INVALID_ARGUMENT, "no compressed tables were given");
+    e->dp.variant = variant == 0 ? 0 : 1;
+    e->dp.use_ctab = variant == 2 ? 1 : 0;
     return LCF_OK;
 }
 
@@ -838,9 +890,11 @@ lcf_status lcf_blackbody_to_filters(lcf_engine* e, int64_t m, const int32_t* fil
     LCF_HIP(hipMemcpyAsync(dF, filt_idx, m * sizeof(int), hipMemcpyHostToDevice, e->stream));
     const dim3 grid((unsigned)((m + kBlock - 1) / kBlock));
     if (e->dp.variant == 0)
-        hipLaunchKernelGGL(k_bb_pointwise<0>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, dT, dR, dO);
+        hipLaunchKernelGGL(k_bb_pointwise<0>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, e->d_ctab_off,
+                           e->d_ctmin, dT, dR, dO);
     else
-        hipLaunchKernelGGL(k_bb_pointwise<1>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, dT, dR, dO);
+        hipLaunchKernelGGL(k_bb_pointwise<1>, grid, dim3(kBlock), 0, e->stream, e->dp, (int)m, dF, e->d_tab_off, e->d_ctab_off,
+                           e->d_ctmin, dT, dR, dO);
     LCF_HIP(hipGetLastError());
     LCF_HIP(hipMemcpyAsync(out, dO, m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 1
+LCF_ABI_VERSION = 2
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -43,7 +43,8 @@ class LcfProblem(C.Structure):
                 ('sigma_type', C.c_int32), ('n_filters', C.c_int32), ('n_points', C.c_int64),
                 ('consts', C.c_double * N_CONSTS),
                 ('t', _dp), ('y', _dp), ('dy', _dp), ('filt_idx', _ip), ('tab_off', _ip), ('tab_a', _dp),
-                ('tab_w', _dp), ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
+                ('tab_w', _dp), ('ctab_off', _ip), ('ctab_a', _dp), ('ctab_w', _dp), ('ctab_tmin', _dp),
+                ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
                 ('n_knots', C.c_int32), ('reserved', C.c_int32), ('spline_knots', _dp), ('spline_coef', _dp),
                 ('priors', C.POINTER(LcfPrior))]
 
@@ -151,7 +152,7 @@ class Engine:
     ``(kind, p_min, p_max, mean, stddev)`` or ``None``."""
 
     def __init__(self, model_id, n_par, consts, t, y, dy, filt_idx, tab_off, tab_a, tab_w, use_sigma=False,
-                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0):
+                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -171,6 +172,12 @@ class Engine:
         pr.t, pr.y, pr.dy = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
         pr.filt_idx, pr.tab_off = _ptr(keep[3], _ip), _ptr(keep[4], _ip)
         pr.tab_a, pr.tab_w = _ptr(keep[5]), _ptr(keep[6])
+        if ctab is not None:  # (coff, ca, cw, ctmin): Gauss-compressed companions of the band tables
+            cx = [_i32(ctab[0]), _f64(ctab[1]), _f64(ctab[2]), _f64(ctab[3])]
+            if len(cx[0]) != pr.n_filters + 1 or len(cx[3]) != pr.n_filters or len(cx[1]) != len(cx[2]):
+                raise ValueError('inconsistent compressed tables')
+            keep += cx
+            pr.ctab_off, pr.ctab_a, pr.ctab_w, pr.ctab_tmin = _ptr(cx[0], _ip), _ptr(cx[1]), _ptr(cx[2]), _ptr(cx[3])
         if companion is not None:
             kp, sp, dtp, knots, coef = companion
             extra = [_i32(kp), _i32(sp), _i32(dtp), _f64(knots), _f64(coef)]

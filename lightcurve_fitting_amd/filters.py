@@ -59,6 +59,65 @@ def trapezoid_weights(x):
     return w
 
 
+def gauss_rule(x, w, m):
+    """``m``-point Gauss quadrature of the discrete measure ``sum_k w_k delta(x - x_k)`` (all ``w_k > 0``): nodes
+    ``xg`` and positive weights ``wg`` with ``sum_j wg_j p(xg_j) == sum_k w_k p(x_k)`` for every polynomial ``p`` of
+    degree < 2m.  Lanczos tridiagonalisation of ``diag(x)`` started from ``sqrt(w)`` with full reorthogonalisation
+    in extended precision, then the Golub-Welsch eigenproblem."""
+    ld = np.longdouble
+    x = np.asarray(x, dtype=ld)
+    w = np.asarray(w, dtype=ld)
+    mu0 = w.sum()
+    basis = [np.sqrt(w / mu0)]
+    alpha, beta = [], []
+    for j in range(m):
+        v = x * basis[j]
+        alpha.append((basis[j] * v).sum())
+        v = v - alpha[j] * basis[j] - (beta[j - 1] * basis[j - 1] if j else 0)
+        for _ in range(2):
+            for q in basis:
+                v = v - (q * v).sum() * q
+        beta.append(np.sqrt((v * v).sum()))
+        basis.append(v / beta[j])
+    off = np.array(beta[:-1], dtype=np.float64)
+    jac = np.diag(np.array(alpha, dtype=np.float64)) + np.diag(off, 1) + np.diag(off, -1)
+    nodes, vecs = np.linalg.eigh(jac)
+    return nodes, float(mu0) * vecs[0] ** 2
+
+
+#: relative accuracy the compressed band sum must reach against the full sum wherever it is used
+COMPRESSION_TOL = 2e-14
+_T_GRID = np.geomspace(0.2, 2e4, 101)
+
+
+def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32)):
+    """Shorter table ``(a', W')`` with ``sum W'/(e^{a'/T} - 1) == sum W/(e^{a/T} - 1)`` to ``tol`` for every
+    temperature ``T >= t_min``: the Gauss rule of the table's own discrete measure (1/(e^{a/T} - 1) is analytic in a,
+    so a rule exact to polynomial degree 2m-1 converges geometrically in m; it degrades only when the band spans many
+    e-folds, i.e. at low T).  Returns ``(a', W', t_min)`` or ``None`` when no order up to K/2 reaches ``tol`` at 2 kK.
+    Verified here against the full sum on a temperature grid; the engine uses the full table below ``t_min``."""
+    a = np.asarray(a, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    with np.errstate(over='ignore'):
+        full = np.array([np.sum(w / np.expm1(a / t)) for t in _T_GRID])
+    for m in orders:
+        if 2 * m > len(a):
+            break
+        ag, wg = gauss_rule(a, w, m)
+        if not (np.all(wg > 0.) and np.all(ag > 0.)):
+            continue
+        with np.errstate(over='ignore'):
+            comp = np.array([np.sum(wg / np.expm1(ag / t)) for t in _T_GRID])
+        ok = np.abs(comp - full) <= tol * np.abs(full)
+        bad = np.nonzero(~ok)[0]
+        first_good = 0 if len(bad) == 0 else bad[-1] + 1
+        if first_good < len(_T_GRID) and _T_GRID[first_good] <= 2.0:
+            # one grid step of margin above the last failing temperature
+            t_min = _T_GRID[min(first_good + 1, len(_T_GRID) - 1)] if len(bad) else 0.
+            return np.ascontiguousarray(ag[::-1]), np.ascontiguousarray(wg[::-1]), float(t_min)
+    return None
+
+
 @total_ordering
 class Filter:
     """A broadband filter: identity, zero point and (lazily loaded) normalised transmission curve.
@@ -255,7 +314,7 @@ def as_filter(f):
 class PackedTables:
     """Concatenated ``(a_k, W_k)`` tables for a list of distinct filters (CSR layout: ``off[i]:off[i+1]``)."""
 
-    def __init__(self, filters, z=0., cutoff_freq=np.inf, drop_zeros=True):
+    def __init__(self, filters, z=0., cutoff_freq=np.inf, drop_zeros=True, compress=True):
         self.filters = [as_filter(f) for f in filters]
         a_parts, w_parts, off = [], [], [0]
         for f in self.filters:
@@ -268,6 +327,22 @@ class PackedTables:
         self.off = np.asarray(off, dtype=np.int32)
         self.z = z
         self.cutoff_freq = cutoff_freq
+        # Gauss-compressed companions (empty slice + t_min = inf where a filter is too narrow to gain)
+        ca, cw, coff, tmin = [], [], [0], []
+        for i in range(len(self.filters)):
+            a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
+            comp = compress_planck_table(a, w) if compress and len(a) >= 24 else None
+            if comp is None:
+                tmin.append(np.inf)
+            else:
+                ca.append(comp[0])
+                cw.append(comp[1])
+                tmin.append(comp[2])
+            coff.append(coff[-1] + (0 if comp is None else len(comp[0])))
+        self.ca = np.concatenate(ca) if ca else np.zeros(0)
+        self.cw = np.concatenate(cw) if cw else np.zeros(0)
+        self.coff = np.asarray(coff, dtype=np.int32)
+        self.ctmin = np.asarray(tmin, dtype=np.float64)
 
     def index(self, f):
         return self.filters.index(as_filter(f))

@@ -208,7 +208,8 @@ class Model:
         pri = None if priors is None else [p.descriptor() for p in priors]
         return _eng.Engine(self.model_id, self.n_model_params, self._consts(), t, y, dy, idx, tabs.off, tabs.a, tabs.w,
                            use_sigma=use_sigma, sigma_type=st, priors=pri,
-                           companion=self._companion_tables(uniq), device=self.device if device is None else device)
+                           companion=self._companion_tables(uniq), device=self.device if device is None else device,
+                           ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):
         """Engine bound to ``lc`` (cached per light-curve object, sigma mode and prior set)."""
@@ -502,7 +503,7 @@ def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0.):
     uniq, idx = _index_filters(filts)
     tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
     eng = _eng.Engine(_eng.MODEL_BLACKBODY, 2, [], np.zeros(1), np.zeros(1), np.ones(1), np.zeros(1, dtype=np.int32),
-                      tabs.off, tabs.a, tabs.w)
+                      tabs.off, tabs.a, tabs.w, ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
     try:
         if T.ndim == 1 and len(T) == len(filts):
             return eng.blackbody_to_filters(idx, T, R)

@@ -14,7 +14,7 @@ TOL = 1e-11
 VARIANTS = {'n15': dict(n=1.5), 'n3': dict(n=3.), 'rw': dict(RW=True), 'n3rw': dict(n=3., RW=True)}
 
 
-@pytest.fixture(params=[1, 0], ids=['fast', 'libm'])
+@pytest.fixture(params=[2, 1, 0], ids=['gauss', 'fast', 'libm'])
 def variant(request):
     return request.param
 

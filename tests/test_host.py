@@ -50,6 +50,39 @@ def test_filter_curves_and_packed_tables():
         F.as_filter('no-such-filter')
 
 
+def test_gauss_compressed_tables_reproduce_the_full_band_sum():
+    """Every compressed table (Gauss rule of the full table's discrete measure) against the full sum, on and above its
+    validity threshold, and against the reference's synthesize() numbers."""
+    names = [f.name for f in F.all_filters if f.filename]
+    tabs = F.PackedTables(names, z=0.002)
+    n_comp = 0
+    for i, n in enumerate(names):
+        a, w = tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]]
+        ca, cw = tabs.ca[tabs.coff[i]:tabs.coff[i + 1]], tabs.cw[tabs.coff[i]:tabs.coff[i + 1]]
+        if len(ca) == 0:
+            assert np.isinf(tabs.ctmin[i])
+            continue
+        n_comp += 1
+        assert len(ca) <= len(a) // 2 and np.all(cw > 0) and np.all(ca > 0) and np.all(np.diff(ca) < 0)
+        assert np.sum(cw) == pytest.approx(np.sum(w), rel=1e-13)
+        for T in np.concatenate([[max(tabs.ctmin[i], 0.3)], np.geomspace(max(tabs.ctmin[i], 0.3), 5e3, 23)]):
+            full, comp = np.sum(w / np.expm1(a / T)), np.sum(cw / np.expm1(ca / T))
+            assert abs(comp - full) <= 4e-14 * full, (n, T)
+    assert n_comp >= 50
+    p = golden('primitives')
+    for i, n in enumerate([str(x) for x in p['synth/names']]):
+        j = names.index(F.filtdict[n].name)
+        ca, cw = tabs.ca[tabs.coff[j]:tabs.coff[j + 1]], tabs.cw[tabs.coff[j]:tabs.coff[j + 1]]
+        ok = p['synth/T'] >= tabs.ctmin[j]
+        if len(ca) and ok.any():
+            mine = p['synth/R'][ok] ** 2 * np.array([np.sum(cw / np.expm1(ca / t)) for t in p['synth/T'][ok]])
+            assert relerr(mine, p['synth/z0.002'][i][ok]) < 1e-12
+    x, w = np.linspace(1., 2., 40), np.linspace(1., 3., 40)
+    xg, wg = F.gauss_rule(x, w, 6)
+    for deg in range(12):  # exact for polynomials of degree < 2m
+        assert np.sum(wg * xg ** deg) == pytest.approx(np.sum(w * x ** deg), rel=1e-13)
+
+
 def test_not_a_knot_spline_matches_scipy_coefficients():
     c = golden('companion')
     lum = c['csb/lum']
