@@ -43,7 +43,8 @@ struct DevProblem {
     int model, n_points, n_chunks, n_filters;
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
-    int n_epochs, use_therm, use_ctab, pad1;
+    int n_epochs, use_therm, use_ctab, n_tab;
+    int n_parts, cpb, pad2, pad3;  // workgroups per walker, point chunks per workgroup
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double sigma_unit_abs;  // median(dy)
@@ -51,18 +52,13 @@ struct DevProblem {
     const double* t;
     const double* y;
     const double* dy;
-    const int* pt_off;   // first table sample of the point's filter
-    const int* pt_cnt;   // number of table samples
-    const int* pt_coff;  // compressed table of the point's filter: first sample, count, validity threshold [kK]
-    const int* pt_ccnt;
-    const double* pt_tmin;
+    const double* inv_dy;     // 1 / dy
+    const int4* pt_desc;      // tables of the point's filter: (full offset, full count, compressed offset, count)
+    const double* pt_inv_tmin;  // 1 / (lowest temperature at which the compressed table is valid); 0 = never
     const int* pt_filt;  // filter index
     const int* pt_orig;  // index in the caller's order
     const int* pt_epoch; // index into epoch_t (distinct observation times)
     const double* epoch_t; // [n_epochs]
-    const int* chunk_lo; // per chunk: first table sample needed
-    const int* chunk_n;  // per chunk: number of table samples needed
-    const int* chunk_order;  // chunks by descending cost (longest-processing-time-first dispatch)
     const double* exp2tab;   // 2^(j/256), j = 0..255
     const double2* tab;  // (a_k, W_k)
     const int* f_kpar;

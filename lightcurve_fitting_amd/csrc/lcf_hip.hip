@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -47,48 +48,38 @@ __global__ void k_prepare(const DevProblem pb, int n, const double* __restrict__
     lprior[w] = with_prior ? walker_log_prior(pb, p) : 0.;
 }
 
-struct PointOut {
-    double yfit;
-    double T;
-    double pref;
-};
-
 // The two tables of a point's filter (offsets relative to `base`): the full one and its Gauss-compressed companion,
-// valid for T >= tmin.
+// valid for 1/T <= inv_tmin.
 template <class TabPtr>
 struct TabSel {
     TabPtr base;
     int off, cnt, coff, ccnt;
-    double tmin;
+    double inv_tmin;
 };
 
 template <int VARIANT, class TabPtr>
-__device__ inline double band_sum_at(const TabSel<TabPtr>& ts, bool use_ctab, double T, const ExpTab et) {
-    const bool c = use_ctab && T >= ts.tmin;
+__device__ inline double band_sum_at(const TabSel<TabPtr>& ts, bool use_ctab, double invT, const ExpTab et) {
+    const bool c = use_ctab && invT <= ts.inv_tmin;
     const TabPtr tab = ts.base + (c ? ts.coff : ts.off);
     const int cnt = c ? ts.ccnt : ts.cnt;
-    const double invT = 1. / T;
     return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
 }
 
-// Everything one lane does for its data point after the thermal state: band sum(s) -> template term.
+// Everything one lane does for its data point after the thermal state (1/T, R_bb^2): band sum(s) -> template term.
 template <int VARIANT, class TabPtr>
-__device__ inline PointOut point_model(const DevProblem& pb, const double* __restrict__ c,
-                                       const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
-                                       const ExpTab et, double T, double pref) {
-    PointOut o;
-    o.T = T;
-    o.pref = pref;
+__device__ inline double point_model(const DevProblem& pb, const double* __restrict__ c,
+                                     const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
+                                     const ExpTab et, double invT, double pref) {
     double S = 0.;
-    if (o.T > 0.) {
-        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, o.T, et);
+    if (invT > 0.) {
+        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT, et);
         if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
-            const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 0.74 * o.T, et);
+            const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT * (1. / 0.74), et);
             S = fmin(S, S2 * (1. / (0.74 * 0.74 * 0.74 * 0.74)));
         }
     }
-    // pref may be NaN (propagates) or 0 with T == 0.
-    o.yfit = (o.pref != o.pref) ? o.pref : o.pref * S;
+    // pref may be NaN (propagates) or 0 with 1/T == 0.
+    double yfit = (pref != pref) ? pref : pref * S;
     if (pb.model >= kCompanion && pb.model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
         const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
         const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
@@ -96,9 +87,9 @@ __device__ inline PointOut point_model(const DevProblem& pb, const double* __res
         const double dt = dp >= 0 ? p[dp] : 0.;
         const double x = (t_in - c[3] - dt) / c[4];
         const double tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x);
-        o.yfit = o.yfit * kfac + tmpl * sfac;
+        yfit = yfit * kfac + tmpl * sfac;
     }
-    return o;
+    return yfit;
 }
 
 // Thermal state (T, R_bb^2) of every (walker, distinct observation time): light curves observed in several filters at
@@ -114,10 +105,13 @@ __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_l
     if (skip_excluded && lprior[w] == -INFINITY) return;
     double T, pref;
     thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, pref);
-    therm[(size_t)w * pb.n_epochs + ep] = make_double2(T, pref);
+    therm[(size_t)w * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
 }
 
-// MODE 0: chi^2 partial sums -> part[w][chunk];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
+// MODE 0: chi^2 partial sums -> part[w][n_parts];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
+// Workgroup = (walker w, part j): it walks the point chunks j, j + n_parts, j + 2 n_parts, ... (a strided share, so
+// that every workgroup sees a similar mix of filters) with the exp table and ALL band tables staged in LDS once, and
+// reduces once at the end.
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
 __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
                                                    const double* __restrict__ coef,
@@ -129,67 +123,69 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
     double* red = exptab + kExpTabSize;                                   // 4 doubles
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
 
-    // heaviest chunks (widest band tables) are dispatched first so that the grid drains evenly
-    const int chunk = pb.chunk_order[blockIdx.x / n_w];
+    const int part = blockIdx.x / n_w;
     const int w = w_lo + blockIdx.x % n_w;
     const int tid = threadIdx.x;
 
     if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
 
     if (VARIANT == 1 && tid < kExpTabSize) exptab[tid] = pb.exp2tab[tid];
-    const int tlo = pb.chunk_lo[chunk];
-    if (LDS_TAB) {
-        const int tn = pb.chunk_n[chunk];
-        for (int k = tid; k < tn; k += kBlock) ltab[k] = pb.tab[tlo + k];
-    }
+    if (LDS_TAB)
+        for (int k = tid; k < pb.n_tab; k += kBlock) ltab[k] = pb.tab[k];
     __syncthreads();
 
     const double* c = coef + (size_t)w * kNCoef;   // wave-uniform -> scalar loads
     const double* p = P + (size_t)w * pb.n_dim;
     const ExpTab et{exptab};
+    const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
 
-    const int i = chunk * kBlock + tid;
     double term = 0.;
-    if (i < pb.n_points) {
-        const double t_in = pb.t[i];
+    for (int k = 0; k < pb.cpb; ++k) {
+        const int chunk = part + k * pb.n_parts;
+        if (chunk >= pb.n_chunks) break;
+        const int i = chunk * kBlock + tid;
+        if (i >= pb.n_points) continue;
+        const int4 ds = pb.pt_desc[i];
+        const TabSel<const double2*> ts{tbase, ds.x, ds.y, ds.z, ds.w, pb.pt_inv_tmin[i]};
         const int filt = pb.pt_filt[i];
-        PointOut o;
-        double T, pref;
-        if (THERM) {
+        const double t_in = pb.t[i];
+        double invT, pref, Tk = 0.;
+        if (THERM && MODE != 2) {
             const double2 tp = therm[(size_t)w * pb.n_epochs + pb.pt_epoch[i]];
-            T = tp.x;
+            invT = tp.x;
             pref = tp.y;
         } else {
-            thermal_state(pb, c, t_in, T, pref);
+            thermal_state(pb, c, t_in, Tk, pref);
+            invT = Tk > 0. ? 1. / Tk : 0.;
         }
-        const TabSel<const double2*> ts{LDS_TAB ? (const double2*)ltab - tlo : pb.tab, pb.pt_off[i], pb.pt_cnt[i],
-                                        pb.pt_coff[i], pb.pt_ccnt[i], pb.pt_tmin[i]};
-        o = point_model<VARIANT>(pb, c, p, t_in, filt, ts, et, T, pref);
-        if (MODE == 0) {  // models.py:121-135
-            const double dy = pb.dy[i];
-            const double r = pb.y[i] - o.yfit;
-            if (pb.use_sigma) {
-                const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
-                const double var = fma(dy, dy, su * su);
-                term = log(kTwoPi * var) + r * r / var;
-            } else {
-                const double q = r / dy;
-                term = q * q;
-            }
-        } else if (MODE == 1) {
-            out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = o.yfit;
-        } else {
+        if (MODE == 2) {
             // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
             const size_t j = (size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i];
-            out0[j] = o.T;
-            out1[j] = sqrt(o.pref);
+            out0[j] = Tk;
+            out1[j] = sqrt(pref);
+            continue;
+        }
+        const double yfit = point_model<VARIANT>(pb, c, p, t_in, filt, ts, et, invT, pref);
+        if (MODE == 0) {  // models.py:121-135
+            const double r = pb.y[i] - yfit;
+            if (pb.use_sigma) {
+                const double dy = pb.dy[i];
+                const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
+                const double var = fma(dy, dy, su * su);
+                term += log(kTwoPi * var) + r * r / var;
+            } else {
+                const double q = r * pb.inv_dy[i];
+                term = fma(q, q, term);
+            }
+        } else {
+            out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = yfit;
         }
     }
     if (MODE == 0) {
         const double ws = wave_sum(term);
         if ((tid & 63) == 0) red[tid >> 6] = ws;
         __syncthreads();
-        if (tid == 0) out0[(size_t)w * pb.n_chunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) out0[(size_t)w * pb.n_parts + part] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -204,7 +200,7 @@ __global__ void k_finalize(const DevProblem pb, int n, const double* __restrict_
         return;
     }
     double s = pb.use_sigma ? 0. : pb.log_norm_const;
-    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)w * pb.n_chunks + k];
+    for (int k = 0; k < pb.n_parts; ++k) s += part[(size_t)w * pb.n_parts + k];
     out[w] = lp - 0.5 * s;
 }
 
@@ -227,8 +223,8 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
     if (Tk > 0. && Tk < kTmax) {
         const ExpTab et{exptab};
         const TabSel<const double2*> ts{pb.tab, tab_off[2 * f], tab_off[2 * f + 1], ctab_off[2 * f],
-                                        ctab_off[2 * f + 1], ctmin[f]};
-        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, Tk, et);
+                                        ctab_off[2 * f + 1], 1. / ctmin[f]};
+        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 1. / Tk, et);
     }
     out[i] = r * r * S;
 }
@@ -239,6 +235,26 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
 // parallel and without any inter-workgroup hand-off, (i) commit the previous half-step and (ii) draw the next
 // proposals: a thread that needs the position of a walker whose previous move is not committed yet simply evaluates
 // that walker's accept test itself (a pure function of immutable per-slot data).
+// Per proposal slot: what its accept test needs besides the new log-posterior (one 32-byte load).
+struct SlotRec {
+    double zl;      // (n_dim - 1) ln z
+    double lnu;     // ln u of the accept test
+    double lp_old;  // log-posterior of the walker when the proposal was drawn
+    double lpri;    // log-prior of the proposal
+};
+// Per walker: its latest proposal among the half-steps of one parity (one 16-byte load).
+struct LastRec {
+    long long g;  // half-step (-1: none)
+    int slot, pad;
+};
+// Per (step, half, slot): the state-independent part of the stretch move, drawn for the whole run in advance.
+struct DrawRec {
+    int wid, pid;  // active walker and its partner from the complementary colour
+    double z;      // stretch factor
+    double zl;     // (n_dim - 1) ln z
+    double lnu;    // ln u
+};
+
 struct DevSampler {
     int n_walkers, n_half, n_dim, store_chain;
     uint32_t key0, key1;
@@ -248,15 +264,11 @@ struct DevSampler {
     double* X;          // [n_walkers][n_dim]  committed positions
     double* LP;         // [n_walkers]         committed log-posteriors
     double* Q[2];       // [n_half][n_dim]     proposals
-    double* zl[2];      // [n_half]            (n_dim - 1) ln z
-    double* lnu[2];     // [n_half]            ln u of the accept test
-    double* lp_old[2];  // [n_half]            log-posterior of the walker when the proposal was drawn
-    double* lpri[2];    // [n_half]            log-prior of the proposal
+    SlotRec* rec[2];    // [n_half]
     double* newlp[2];   // [n_half]            log-posterior of the proposal (finalize kernel / all-gather)
     int* act[2];        // [n_half]            walker id of each slot
-    int* last_slot[2];     // [n_walkers]      slot of the walker's latest proposal among half-steps of this parity
-    long long* last_g[2];  // [n_walkers]      ... and the half-step it belongs to (-1: none)
-    const double* part; // [n_half][n_chunks]  chi^2 partial sums of the latest evaluation
+    LastRec* last[2];   // [n_walkers]
+    const double* part; // [n_half][n_parts]   chi^2 partial sums of the latest evaluation
     double* chain;      // [n_steps][n_walkers][n_dim]
     double* chain_lp;   // [n_steps][n_walkers]
     long long* nacc;    // [n_walkers]
@@ -308,26 +320,48 @@ __device__ inline double finalize_one(const DevProblem& pb, const double* __rest
     const double lp = lprior[i];
     if (lp == -INFINITY) return -INFINITY;
     double s = pb.use_sigma ? 0. : pb.log_norm_const;
-    for (int k = 0; k < pb.n_chunks; ++k) s += part[(size_t)i * pb.n_chunks + k];
+    for (int k = 0; k < pb.n_parts; ++k) s += part[(size_t)i * pb.n_parts + k];
     return lp - 0.5 * s;
 }
 
-// Accept test of proposal `slot` of the half-step with parity pp: emcee's  (ndim-1) ln z + lp_new - lp_old > ln u.
-__device__ inline bool decide(const DevProblem& pb, const DevSampler& sm, int pp, int slot, double& nlp) {
-    nlp = sm.inline_finalize ? finalize_one(pb, sm.part, sm.lpri[pp], slot) : sm.newlp[pp][slot];
-    return (sm.zl[pp][slot] + nlp - sm.lp_old[pp][slot]) > sm.lnu[pp][slot];
+// The state-independent half of every stretch move of a run, one thread per (step, half, slot).
+__global__ void k_draws(DevSampler sm, const int* __restrict__ perm, long long first_step, long long n_steps,
+                        DrawRec* __restrict__ draws) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_steps * 2 * sm.n_half) return;
+    const int i = (int)(idx % sm.n_half), half = (int)((idx / sm.n_half) & 1);
+    const long long row = idx / (2 * sm.n_half);
+    const int* pr = perm ? perm + (size_t)row * sm.n_walkers : nullptr;
+    const int n_other = sm.n_walkers - sm.n_half;
+    const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
+    const int wid = pr ? pr[my_slot] : my_slot;
+    uint32_t r[4], s2[4];
+    philox4x32((uint32_t)wid, (uint32_t)(first_step + row), (uint32_t)half, 0u, sm.key0, sm.key1, r);
+    philox4x32((uint32_t)wid, (uint32_t)(first_step + row), (uint32_t)half, 1u, sm.key0, sm.key1, s2);
+    const double zr = (sm.a - 1.) * u01(r[0], r[1]) + 1.;
+    const double z = zr * zr / sm.a;
+    int j = (int)(u01(r[2], r[3]) * (double)n_other);
+    j = min(j, n_other - 1);
+    const int other_slot = half == 0 ? sm.n_half + j : j;
+    DrawRec d;
+    d.wid = wid;
+    d.pid = pr ? pr[other_slot] : other_slot;
+    d.z = z;
+    d.zl = (double)(sm.n_dim - 1) * log(z);
+    d.lnu = log(u01(s2[0], s2[1]));
+    draws[idx] = d;
 }
 
 // One workgroup per (proposal slot i, epoch chunk): wave 0 commits half-step g - 1 for slot i (chunk 0 only) and draws
 // slot i of half-step g COOPERATIVELY -- the latency chain of a single thread (three accept tests with dependent
-// loads, then six logarithms) is spread over lanes that run the same code on different data:
-//   lanes 0..2: accept test of {previous slot i, own walker, partner walker};  lanes 0..n_par+1: the logarithms of
-//   the proposal's parameters, of z and of u.
+// loads, then the logarithms of the proposal) is spread over lanes that run the same code on different data:
+//   lanes 0..2: accept test of {previous slot i, own walker, partner walker}, with every load that does not depend
+//   on the outcome issued up front (both candidate rows included);  lanes 0..n_par-1: ln of the proposal's parameters.
 // Every lane ends with the same proposal (bitwise); lane 0 of the chunk-0 workgroup publishes it.  Then all 256
 // threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
 __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
-                                                 long long prev_row, int have_next, const int* __restrict__ perm,
-                                                 long long g, long long step, int half, int lo, int hi,
+                                                 long long prev_row, int have_next,
+                                                 const DrawRec* __restrict__ draws, long long g, int lo, int hi,
                                                  int n_echunks, int do_thermal, double* __restrict__ coef,
                                                  double* __restrict__ lprior, double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
@@ -335,43 +369,46 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
     const bool in_shard = do_thermal && i >= lo && i < hi;
     if (ec > 0 && !in_shard) return;
     const int lane = threadIdx.x;
+    const int ep = ec * kBlock + lane;
+    const double t_ep = (in_shard && ep < pb.n_epochs) ? pb.epoch_t[ep] : 0.;  // issued before the serial section
     if (lane < 64) {
         const int pp = (int)((g - 1) & 1), cp = (int)(g & 1), nd = sm.n_dim;
-        int wid = 0, pid = 0;
-        double z = 1., u = 0.5;
-        if (have_next) {
-            const int n_other = sm.n_walkers - sm.n_half;
-            const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
-            wid = perm ? perm[my_slot] : my_slot;
-            uint32_t r[4], s2[4];
-            philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 0u, sm.key0, sm.key1, r);
-            philox4x32((uint32_t)wid, (uint32_t)step, (uint32_t)half, 1u, sm.key0, sm.key1, s2);
-            const double zr = (sm.a - 1.) * u01(r[0], r[1]) + 1.;
-            z = zr * zr / sm.a;
-            u = u01(s2[0], s2[1]);
-            int j = (int)(u01(r[2], r[3]) * (double)n_other);
-            j = min(j, n_other - 1);
-            const int other_slot = half == 0 ? sm.n_half + j : j;
-            pid = perm ? perm[other_slot] : other_slot;
-        }
+        DrawRec dr{0, 0, 1., 0., 0.};
+        if (have_next) dr = draws[i];
         // --- roles: which accept test (if any) this lane evaluates ---
         int rw = -1, rslot = -1;
         if (lane == 0 && have_prev && ec == 0) {
             rslot = i;
             rw = sm.act[pp][i];
         } else if ((lane == 1 || lane == 2) && have_next) {
-            rw = lane == 1 ? wid : pid;
-            if (sm.last_g[pp][rw] == g - 1) rslot = sm.last_slot[pp][rw];
+            rw = lane == 1 ? dr.wid : dr.pid;
+            const LastRec lr = sm.last[pp][rw];
+            if (lr.g == g - 1) rslot = lr.slot;
         }
-        double nlp = 0.;
+        double row[kMaxDim], qrow[kMaxDim], lp_cur = 0., nlp = 0.;
         bool ok = false;
-        if (rslot >= 0) ok = decide(pb, sm, pp, rslot, nlp);
-        double row[kMaxDim], lp_cur = 0.;
-        for (int d = 0; d < kMaxDim; ++d) row[d] = 0.;
+        for (int d = 0; d < kMaxDim; ++d) row[d] = qrow[d] = 0.;
         if (rw >= 0) {
-            const double* src = ok ? sm.Q[pp] + (size_t)rslot * nd : sm.X + (size_t)rw * nd;
-            for (int d = 0; d < nd; ++d) row[d] = src[d];
-            lp_cur = rslot >= 0 ? (ok ? nlp : sm.lp_old[pp][rslot]) : sm.LP[rw];
+            // everything the accept test and both outcomes need, in one wave of loads
+            const double* xs = sm.X + (size_t)rw * nd;
+            for (int d = 0; d < nd; ++d) row[d] = xs[d];
+            lp_cur = sm.LP[rw];
+            if (rslot >= 0) {
+                const SlotRec rc = sm.rec[pp][rslot];
+                const double* qs = sm.Q[pp] + (size_t)rslot * nd;
+                for (int d = 0; d < nd; ++d) qrow[d] = qs[d];
+                if (sm.inline_finalize) {
+                    double sum = pb.use_sigma ? 0. : pb.log_norm_const;
+                    for (int k = 0; k < pb.n_parts; ++k) sum += sm.part[(size_t)rslot * pb.n_parts + k];
+                    nlp = rc.lpri == -INFINITY ? -INFINITY : rc.lpri - 0.5 * sum;
+                } else {
+                    nlp = sm.newlp[pp][rslot];
+                }
+                ok = (rc.zl + nlp - rc.lp_old) > rc.lnu;  // emcee: (ndim-1) ln z + lp_new - lp_old > ln u
+                lp_cur = ok ? nlp : rc.lp_old;
+                if (ok)
+                    for (int d = 0; d < nd; ++d) row[d] = qrow[d];
+            }
         }
         if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
             if (nlp != nlp) atomicExch(sm.err, 1);
@@ -391,15 +428,12 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
             double arg = 1.;
             for (int d = 0; d < kMaxDim; ++d) {
                 const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
-                q[d] = d < nd ? cj - (cj - xi) * z : 0.;
+                q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
                 if (lane == d && d < pb.n_par) arg = q[d];
             }
             const double lp_i = __shfl(lp_cur, 1, 64);
-            if (lane == pb.n_par) arg = z;
-            if (lane == pb.n_par + 1) arg = u;
             const double lg = log(arg);  // one logarithm per lane, all at once
             for (int d = 0; d < kMaxDim; ++d) lq[d] = __shfl(lg, d, 64);
-            const double lz = __shfl(lg, pb.n_par, 64), lu = __shfl(lg, pb.n_par + 1, 64);
             double c[kNCoef];
             walker_coefficients(pb, q, lq, c);
             const double lpr = walker_log_prior(pb, q);
@@ -408,13 +442,9 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
                 sc[kNCoef] = lpr;
                 if (ec == 0) {  // publish the per-slot records
                     for (int d = 0; d < nd; ++d) sm.Q[cp][(size_t)i * nd + d] = q[d];
-                    sm.act[cp][i] = wid;
-                    sm.zl[cp][i] = (double)(nd - 1) * lz;
-                    sm.lnu[cp][i] = lu;
-                    sm.lp_old[cp][i] = lp_i;
-                    sm.lpri[cp][i] = lpr;
-                    sm.last_slot[cp][wid] = i;
-                    sm.last_g[cp][wid] = g;
+                    sm.act[cp][i] = dr.wid;
+                    sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
+                    sm.last[cp][dr.wid] = LastRec{g, i, 0};
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
                     lprior[i] = lpr;
                 }
@@ -424,11 +454,10 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
     if (!have_next || !in_shard) return;
     __syncthreads();
     if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
-    const int ep = ec * kBlock + threadIdx.x;
     if (ep >= pb.n_epochs) return;
     double T, pref;
-    thermal_state(pb, sc, pb.epoch_t[ep], T, pref);
-    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T, pref);
+    thermal_state(pb, sc, t_ep, T, pref);
+    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
 }
 
 }  // namespace
@@ -491,7 +520,7 @@ struct lcf_engine {
         LCF_HIP(hipMalloc((void**)&wP, c * dp.n_dim * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wcoef, c * kNCoef * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wlprior, c * sizeof(double)));
-        LCF_HIP(hipMalloc((void**)&wpart, c * dp.n_chunks * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wpart, c * dp.n_parts * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wout, c * sizeof(double)));
         if (dp.use_therm) LCF_HIP(hipMalloc((void**)&wtherm, c * dp.n_epochs * sizeof(double2)));
         cap = c;
@@ -535,7 +564,7 @@ void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const
         hipLaunchKernelGGL(k_thermal, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pb, w_lo, n,
                            coef, lprior, MODE == 0 ? 1 : 0, therm);
     }
-    const dim3 grid((unsigned)((size_t)n * pb.n_chunks));
+    const dim3 grid((unsigned)((size_t)n * pb.n_parts));
     if (pb.variant == 0)
         launch_points_v<0, MODE>(pb, grid, e->lds_bytes, st, w_lo, n, dP, coef, lprior, therm, out0, out1);
     else
@@ -709,31 +738,20 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         hepoch[i] = (int)(std::lower_bound(epochs.begin(), epochs.end(), ht[i]) - epochs.begin());
     const bool all_finite_t = std::all_of(ht.begin(), ht.end(), [](double v) { return std::isfinite(v); });
     const int n_chunks = std::max(1, (N + kBlock - 1) / kBlock);
-    std::vector<int> clo(n_chunks, 0), cn(n_chunks, 0);
-    int max_cn = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int a = c * kBlock, b = std::min(N, a + kBlock);
-        if (a >= b) continue;
-        int lo = hoff[a], hi = hoff[a] + hcnt[a];
-        for (int i = a; i < b; ++i) {
-            lo = std::min(lo, hoff[i]);
-            hi = std::max(hi, hoff[i] + hcnt[i]);
-            if (hccnt[i] > 0) {
-                lo = std::min(lo, hcoff[i]);
-                hi = std::max(hi, hcoff[i] + hccnt[i]);
-            }
-        }
-        clo[c] = lo;
-        cn[c] = hi - lo;
-        max_cn = std::max(max_cn, cn[c]);
-    }
+    // workgroups per walker: enough to fill the chip at a few hundred walkers, few enough to amortise the prologue
+    int n_parts = std::min(n_chunks, 4);
+    if (const char* env = std::getenv("LCF_PARTS")) n_parts = std::max(1, std::min(n_chunks, std::atoi(env)));
+    const int cpb = (n_chunks + n_parts - 1) / n_parts;
+    n_parts = (n_chunks + cpb - 1) / cpb;
     std::vector<int> htaboff(pfull);
     if (htab.empty()) htab.push_back(make_double2(1., 0.));
-    std::vector<int> corder(n_chunks);
-    std::iota(corder.begin(), corder.end(), 0);
-    std::vector<long long> ccost(n_chunks, 0);
-    for (int i = 0; i < N; ++i) ccost[i / kBlock] += (hccnt[i] > 0 ? hccnt[i] : hcnt[i]) + 12;  // samples + overhead
-    std::stable_sort(corder.begin(), corder.end(), [&](int a, int b) { return ccost[a] > ccost[b]; });
+    std::vector<int4> hdesc(N);
+    std::vector<double> hinvdy(N), hinvtmin(N);
+    for (int i = 0; i < N; ++i) {
+        hdesc[i] = make_int4(hoff[i], hcnt[i], hcoff[i], hccnt[i]);
+        hinvdy[i] = 1. / hdy[i];
+        hinvtmin[i] = hccnt[i] > 0 ? 1. / htmin[i] : 0.;  // t_min = 0 -> inf: always valid
+    }
     std::vector<double> hexp(kExpTabSize);
     for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
 
@@ -741,6 +759,9 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.model = pr->model;
     dp.n_points = N;
     dp.n_chunks = n_chunks;
+    dp.n_parts = n_parts;
+    dp.cpb = cpb;
+    dp.n_tab = (int)htab.size();
     dp.n_filters = NF;
     dp.n_dim = n_dim;
     dp.n_par = pr->n_par;
@@ -748,7 +769,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.sigma_abs = pr->sigma_type == LCF_SIGMA_ABSOLUTE;
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
-    dp.tab_in_lds = max_cn <= kLdsTabMax;
+    dp.tab_in_lds = (int)htab.size() <= kLdsTabMax;
     dp.n_epochs = (int)epochs.size();
     dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
     dp.variant = 1;
@@ -758,25 +779,25 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
-    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)std::max(max_cn, 1) * sizeof(double2) : 0);
+    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? htab.size() * sizeof(double2) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
-    int *doff, *dcnt, *dfilt, *dorig, *dclo, *dcn, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
+    int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
     double2* dtab;
     PriorDev* dpri = nullptr;
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
-    UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hoff, doff); UP(hcnt, dcnt); UP(hfilt, dfilt); UP(horig, dorig);
-    UP(clo, dclo); UP(cn, dcn); UP(htab, dtab); UP(htaboff, e->d_tab_off);
-    int *dcord, *depoch, *dcoff, *dccnt;
-    double *dexp, *depocht, *dtmin;
-    UP(corder, dcord); UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
-    UP(hcoff, dcoff); UP(hccnt, dccnt); UP(htmin, dtmin); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
-    dp.pt_coff = dcoff;
-    dp.pt_ccnt = dccnt;
-    dp.pt_tmin = dtmin;
+    UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hfilt, dfilt); UP(horig, dorig);
+    UP(htab, dtab); UP(htaboff, e->d_tab_off);
+    int* depoch;
+    int4* ddesc;
+    double *dexp, *depocht, *dinvdy, *dinvtmin;
+    UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
+    UP(hdesc, ddesc); UP(hinvdy, dinvdy); UP(hinvtmin, dinvtmin); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
+    dp.pt_desc = ddesc;
+    dp.inv_dy = dinvdy;
+    dp.pt_inv_tmin = dinvtmin;
     dp.pt_epoch = depoch;
     dp.epoch_t = depocht;
-    dp.chunk_order = dcord;
     dp.exp2tab = dexp;
     if (companion) {
         std::vector<int> hk(pr->filt_kasen_par, pr->filt_kasen_par + NF), hs(pr->filt_sifto_par, pr->filt_sifto_par + NF),
@@ -797,8 +818,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         UP(hp, dpri);
     }
 #undef UP
-    dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_off = doff; dp.pt_cnt = dcnt; dp.pt_filt = dfilt; dp.pt_orig = dorig;
-    dp.chunk_lo = dclo; dp.chunk_n = dcn; dp.tab = dtab; dp.f_kpar = dk; dp.f_spar = ds; dp.f_dtpar = ddt;
+    dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_filt = dfilt; dp.pt_orig = dorig;
+    dp.tab = dtab; dp.f_kpar = dk; dp.f_spar = ds; dp.f_dtpar = ddt;
     dp.knots = dkn; dp.spl = dspl; dp.priors = dpri;
     *out = e;
     return LCF_OK;
@@ -940,6 +961,8 @@ struct lcf_sampler {
     double2* therm = nullptr;
     int* d_perm = nullptr;
     int64_t perm_rows = 0;  // rows allocated
+    DrawRec* d_draws = nullptr;
+    int64_t draw_rows = 0;
     bool have_perm = false;
     int64_t run_first = 0, run_steps = 0;
     int64_t chain_cap = 0;
@@ -956,6 +979,7 @@ struct lcf_sampler {
         if (ds.chain) hipFree(ds.chain);
         if (ds.chain_lp) hipFree(ds.chain_lp);
         if (d_perm) hipFree(d_perm);
+        if (d_draws) hipFree(d_draws);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
     }
@@ -970,11 +994,6 @@ lcf_status dalloc(T** p, size_t n, std::vector<void*>& owned) {
     return LCF_OK;
 }
 
-const int* perm_row(const lcf_sampler* s, long long g) {
-    if (!s->have_perm) return nullptr;
-    return s->d_perm + (size_t)((g - s->g_run0) / 2) * s->ds.n_walkers;
-}
-
 // Commit half-step g_next - 1 (if pending) and draw half-step g_next (if have_next).  `fuse_thermal`: also evaluate
 // the thermal states of slots [lo, hi) in the same launch.
 lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo, int hi, hipStream_t st) {
@@ -985,15 +1004,13 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     if (!have_prev && !have_next) return LCF_OK;
     const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
     const long long rel = g - s->g_run0;
-    const long long step = s->run_first + rel / 2;
-    const int half = (int)(rel & 1);
-    const int* perm = have_next ? perm_row(s, g) : nullptr;
+    const DrawRec* draws = have_next ? s->d_draws + (size_t)rel * ds.n_half : nullptr;
     const bool thermal = have_next && fuse_thermal && e->dp.use_therm;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
     hipLaunchKernelGGL(k_step, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, e->dp, ds,
-                       have_prev, prev_row, have_next ? 1 : 0, perm, g, step, half, lo, hi, nec, thermal ? 1 : 0,
-                       s->coef, s->lprior, s->therm);
+                       have_prev, prev_row, have_next ? 1 : 0, draws, g, lo, hi, nec, thermal ? 1 : 0, s->coef,
+                       s->lprior, s->therm);
     LCF_HIP(hipGetLastError());
     s->pending = have_next;
     if (have_next) s->g_next = g + 1;
@@ -1009,7 +1026,7 @@ lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool f
     if (finalize) {
         const int bs = 128;
         hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
-                           s->part + (size_t)lo * e->dp.n_chunks, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
+                           s->part + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
     }
     LCF_HIP(hipGetLastError());
     return LCF_OK;
@@ -1044,20 +1061,15 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
     AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.nacc, nw); AL(ds.err, 1);
     for (int b = 0; b < 2; ++b) {
-        AL(ds.last_slot[b], nw); AL(ds.last_g[b], nw);
-        AL(ds.Q[b], nh * nd); AL(ds.zl[b], nh); AL(ds.lnu[b], nh); AL(ds.lp_old[b], nh); AL(ds.lpri[b], nh);
-        AL(ds.newlp[b], nh); AL(ds.act[b], nh);
+        AL(ds.last[b], nw); AL(ds.Q[b], nh * nd); AL(ds.rec[b], nh); AL(ds.newlp[b], nh); AL(ds.act[b], nh);
     }
-    AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_chunks);
+    AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_parts);
     if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
     ds.part = s->part;
     LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
-    for (int b = 0; b < 2; ++b) {
-        LCF_HIP(hipMemset(ds.last_g[b], 0xff, nw * sizeof(long long)));  // -1: no proposal yet
-        LCF_HIP(hipMemset(ds.last_slot[b], 0, nw * sizeof(int)));
-    }
+    for (int b = 0; b < 2; ++b) LCF_HIP(hipMemset(ds.last[b], 0xff, nw * sizeof(LastRec)));  // g = -1: no proposal yet
     LCF_HIP(hipEventCreate(&s->ev0));
     LCF_HIP(hipEventCreate(&s->ev1));
     *out = s;
@@ -1079,7 +1091,7 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
     for (int b = 0; b < 2; ++b)
-        LCF_HIP(hipMemsetAsync(ds.last_g[b], 0xff, (size_t)ds.n_walkers * sizeof(long long), e->stream));
+        LCF_HIP(hipMemsetAsync(ds.last[b], 0xff, (size_t)ds.n_walkers * sizeof(LastRec), e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));
     s->has_state = true;
     return LCF_OK;
@@ -1164,6 +1176,20 @@ lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps
             }
         }
         LCF_HIP(hipMemcpy(s->d_perm, perm, (size_t)n_steps * ds.n_walkers * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (n_steps > 0) {  // state-independent draws of the whole run: (walker, partner, z, ln u) per proposal slot
+        if (n_steps > s->draw_rows) {
+            if (s->d_draws) hipFree(s->d_draws);
+            s->d_draws = nullptr;
+            s->draw_rows = 0;
+            LCF_HIP(hipMalloc((void**)&s->d_draws, (size_t)n_steps * ds.n_walkers * sizeof(DrawRec)));
+            s->draw_rows = n_steps;
+        }
+        const long long total = (long long)n_steps * ds.n_walkers;
+        hipLaunchKernelGGL(k_draws, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds,
+                           s->have_perm ? s->d_perm : nullptr, (long long)first_step, (long long)n_steps, s->d_draws);
+        LCF_HIP(hipGetLastError());
+        LCF_HIP(hipStreamSynchronize(e->stream));
     }
     return LCF_OK;
 }
