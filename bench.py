@@ -61,21 +61,40 @@ def initial_walkers(n):
     return rng.uniform(lo, hi, (n, 5))
 
 
-def committed_pmc():
+def committed_pmc(variant):
     """HBM traffic and VALU utilisation of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_k_points_summary.json, collected by tools/collect_profiles.sh; counters cannot be read from
+    (profiles/r01_pmc_k_points_v<variant>.json, collected by tools/collect_profiles.sh; counters cannot be read from
     inside this process).  FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads
     prescribes (MI355X_MICROARCH.md, HBM section); both are in KiB per launch of 512 walkers."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_k_points_summary.json')
+    path = os.path.join(ROOT, 'profiles', f'r01_pmc_k_points_v{variant}.json')
     try:
         c = {k: v['mean_per_launch'] for k, v in json.load(open(path)).items()}
         traffic = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.
-        # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; SQ counters sample
-        # SQ_WAVES / launched waves of the grid
-        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 12 * 4))
+        # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; the SQ counters cover
+        # SQ_WAVES of the launched waves (512 walkers x 4 workgroups x 4 waves)
+        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 4 * 4))
         return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES']
     except Exception:
         return None, None, None
+
+
+def roofline_entry(engine, x0, shard, variant):
+    """Dominant kernel alone (HIP events on the engine's stream, 50 back-to-back launches) against the FP64 VALU
+    ceiling by the ALGORITHMIC instruction count of SURVEY 8d."""
+    engine.set_variant(variant)
+    kern_ms = engine.profile_loglike_kernel(x0[:shard], reps=50)
+    evals_per_s = shard / (kern_ms * 1e-3)
+    achieved = evals_per_s * ALG_INSTR / 1e12
+    hbm_gbs = evals_per_s * ALG_BYTES / 1e9
+    traffic, valu_util, valu_per_wave = committed_pmc(variant)
+    return {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR, 'unit': 'Tinstr/s',
+            'frac': achieved / PEAK_FP64_TINSTR, 'traffic': traffic,
+            'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
+            'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
+            'kernel': 'k_points<1,0,true,true>', 'band_sum_variant': variant, 'kernel_ms': kern_ms,
+            'walkers_per_launch': shard,
+            'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
+                    'algorithmic_bytes_per_walker_step': ALG_BYTES}}
 
 
 def cpu_baseline(lc, budget_s=12., max_evals=128):
@@ -203,6 +222,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--full-tables-reference', action='store_true',
+                    help='also time the dominant kernel over the full (uncompressed) band tables')
     ap.add_argument('--variant', type=int, default=2,
                     help='band sum: 2 = fused + Gauss-compressed tables (default), 1 = fused over the full tables, 0 = libm')
     args = ap.parse_args()
@@ -261,13 +282,18 @@ def main():
 
     out = None
     if rank == 0:
-        # dominant kernel alone: 512-walker half-step batch of this rank's shard, HIP events on the engine stream
+        # dominant kernel alone: the half-step batch of this rank's shard, for the variant used in the timed region
+        # and, for reference, for the full (uncompressed) band tables
         shard = (n_walkers // 2) // n_gpus
-        kern_ms = engine.profile_loglike_kernel(x0[:shard], reps=50)
-        evals_per_s = shard / (kern_ms * 1e-3)
-        achieved = evals_per_s * ALG_INSTR / 1e12
-        hbm_gbs = evals_per_s * ALG_BYTES / 1e9
-        traffic, valu_util, valu_per_wave = committed_pmc()
+        roof = roofline_entry(engine, x0, shard, args.variant)
+        roof['note'] = ('FP64 vector-ALU lane-instructions, ALGORITHMIC count: 34 per Planck sample of the reference '
+                        "(146000 per evaluation) + 68 per point (SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 "
+                        'TFLOP/s FMA. frac exceeds 1 because the kernel needs far fewer instructions than the '
+                        'convention: ~19 per sample, and with the Gauss-compressed tables (variant 2) 12 samples '
+                        'reproduce the sum over 87 to 2e-14. valu_utilisation_pmc is the measured busy fraction of '
+                        'the vector ALU.')
+        roof_full = roofline_entry(engine, x0, shard, 1) if (args.full_tables_reference and args.variant != 1) else None
+        engine.set_variant(args.variant)
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -278,18 +304,7 @@ def main():
                        'walkers': n_walkers, 'points': ALG_POINTS, 'planck_samples_per_eval': ALG_SAMPLES,
                        'parallelism': f'walker-sharded x{n_gpus}' if n_gpus > 1 else
                        ('single GPU, multi-GPU code path forced' if force_sharded else 'single GPU')},
-            'roofline': {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR,
-                         'unit': 'Tinstr/s', 'frac': achieved / PEAK_FP64_TINSTR,
-                         'note': 'FP64 vector-ALU lane-instructions: algorithmic 34 per Planck sample + 68 per point '
-                                 '(SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 TFLOP/s FMA. frac can exceed 1: the '
-                                 'kernel spends ~15 FP64 + 4 int32 instructions per sample, not the 34 of the convention; '
-                                 'valu_utilisation_pmc is the measured busy fraction of the vector ALU',
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
-                         'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
-                         'kernel': 'k_points<1,0,true,true>', 'kernel_ms': kern_ms,
-                         'walkers_per_launch': shard,
-                         'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                 'frac': hbm_gbs / PEAK_HBM_GBS, 'algorithmic_bytes_per_walker_step': ALG_BYTES}},
+            'roofline': roof, 'roofline_full_tables': roof_full,
             'device_ms_per_step': sampler.last_run_ms / args.steps if n_gpus == 1 else None,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

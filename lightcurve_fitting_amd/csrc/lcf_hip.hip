@@ -140,45 +140,63 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
     const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
 
     double term = 0.;
-    for (int k = 0; k < pb.cpb; ++k) {
-        const int chunk = part + k * pb.n_parts;
-        if (chunk >= pb.n_chunks) break;
-        const int i = chunk * kBlock + tid;
-        if (i >= pb.n_points) continue;
-        const int4 ds = pb.pt_desc[i];
-        const TabSel<const double2*> ts{tbase, ds.x, ds.y, ds.z, ds.w, pb.pt_inv_tmin[i]};
-        const int filt = pb.pt_filt[i];
-        const double t_in = pb.t[i];
-        double invT, pref, Tk = 0.;
-        if (THERM && MODE != 2) {
-            const double2 tp = therm[(size_t)w * pb.n_epochs + pb.pt_epoch[i]];
-            invT = tp.x;
-            pref = tp.y;
-        } else {
-            thermal_state(pb, c, t_in, Tk, pref);
-            invT = Tk > 0. ? 1. / Tk : 0.;
-        }
-        if (MODE == 2) {
-            // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
-            const size_t j = (size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i];
-            out0[j] = Tk;
-            out1[j] = sqrt(pref);
-            continue;
-        }
-        const double yfit = point_model<VARIANT>(pb, c, p, t_in, filt, ts, et, invT, pref);
-        if (MODE == 0) {  // models.py:121-135
-            const double r = pb.y[i] - yfit;
-            if (pb.use_sigma) {
-                const double dy = pb.dy[i];
-                const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
-                const double var = fma(dy, dy, su * su);
-                term += log(kTwoPi * var) + r * r / var;
-            } else {
-                const double q = r * pb.inv_dy[i];
-                term = fma(q, q, term);
+    constexpr int kPre = 4;  // chunks whose operands are fetched together, before any band sum starts
+    for (int k0 = 0; k0 < pb.cpb; k0 += kPre) {
+        int idx[kPre], filt[kPre];
+        int4 desc[kPre];
+        double itm[kPre], tin[kPre], yv[kPre], idy[kPre];
+        double2 th[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int chunk = part + (k0 + u) * pb.n_parts;
+            const int i = chunk * kBlock + tid;
+            idx[u] = (k0 + u < pb.cpb && chunk < pb.n_chunks && i < pb.n_points) ? i : -1;
+            if (idx[u] < 0) continue;
+            desc[u] = pb.pt_desc[i];
+            itm[u] = pb.pt_inv_tmin[i];
+            filt[u] = pb.pt_filt[i];
+            tin[u] = pb.t[i];
+            if (THERM && MODE != 2) th[u] = therm[(size_t)w * pb.n_epochs + pb.pt_epoch[i]];
+            if (MODE == 0) {
+                yv[u] = pb.y[i];
+                idy[u] = pb.use_sigma ? pb.dy[i] : pb.inv_dy[i];
             }
-        } else {
-            out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = yfit;
+        }
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = idx[u];
+            if (i < 0) continue;
+            const TabSel<const double2*> ts{tbase, desc[u].x, desc[u].y, desc[u].z, desc[u].w, itm[u]};
+            double invT, pref, Tk = 0.;
+            if (THERM && MODE != 2) {
+                invT = th[u].x;
+                pref = th[u].y;
+            } else {
+                thermal_state(pb, c, tin[u], Tk, pref);
+                invT = Tk > 0. ? 1. / Tk : 0.;
+            }
+            if (MODE == 2) {
+                // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
+                const size_t j = (size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i];
+                out0[j] = Tk;
+                out1[j] = sqrt(pref);
+                continue;
+            }
+            const double yfit = point_model<VARIANT>(pb, c, p, tin[u], filt[u], ts, et, invT, pref);
+            if (MODE == 0) {  // models.py:121-135
+                const double r = yv[u] - yfit;
+                if (pb.use_sigma) {
+                    const double dy = idy[u];
+                    const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
+                    const double var = fma(dy, dy, su * su);
+                    term += log(kTwoPi * var) + r * r / var;
+                } else {
+                    const double q = r * idy[u];
+                    term = fma(q, q, term);
+                }
+            } else {
+                out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = yfit;
+            }
         }
     }
     if (MODE == 0) {
