@@ -192,6 +192,21 @@ lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int
 void* lcf_sampler_newlp_ptr(lcf_sampler* s);
 lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGPROB if a NaN was seen */
 
+/* ---- native multi-GPU run: RCCL bound at run time -------------------------------------------------------------- */
+/* rccl_path: the librccl.so to dlopen (NULL/"" = the default search path; pass the one PyTorch ships when torch is
+ * in the process).  One rank obtains an id, every rank creates its communicator with it (collective call). */
+typedef struct { char internal[128]; } lcf_comm_id;
+typedef struct lcf_comm lcf_comm;
+lcf_status lcf_comm_unique_id(const char* rccl_path, lcf_comm_id* out);
+lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t n_ranks, int32_t rank, int32_t device,
+                           lcf_comm** out);
+void lcf_comm_destroy(lcf_comm* c);
+/* The whole run of lcf_sampler_run, sharded: this rank evaluates proposals [rank*w, (rank+1)*w) of each half-step
+ * (w = n_walkers / 2 / n_ranks) and one in-place ncclAllGather per half-step makes the ranks agree; enqueued on the
+ * engine's stream without host synchronisation between half-steps.  Collective: same arguments on every rank. */
+lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_step, int64_t n_steps,
+                                   int32_t split_mode, const int32_t* perm, int32_t store_chain);
+
 /* ---- per-epoch blackbody SED likelihood (bolometric.py:154-164: spectrum_mcmc's inner log_posterior) --------- */
 /* For every epoch e, observations ep_off[e] .. ep_off[e+1]-1 (filter index, luminosity density y, uncertainty dy);
  * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged

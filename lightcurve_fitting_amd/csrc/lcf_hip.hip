@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -1261,6 +1262,101 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     LCF_HIP(hipMemcpy(&err, s->ds.err, sizeof(int), hipMemcpyDeviceToHost));
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;
+}
+
+// ---- RCCL, bound at run time (no link-time dependency; the library PyTorch ships is reused when torch is loaded) ----
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, lcf_comm_id, int) = nullptr;  // ncclUniqueId is a 128-byte struct by value
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+lcf_status rccl_load(const char* path) {
+    if (g_rccl.handle) return LCF_OK;
+    void* h = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(LCF_ERR_UNSUPPORTED, std::string("cannot load RCCL: ") + dlerror());
+    Rccl r;
+    r.handle = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+        return fail(LCF_ERR_UNSUPPORTED, "RCCL library lacks the expected symbols");
+    g_rccl = r;
+    return LCF_OK;
+}
+
+lcf_status rccl_check(int rc, const char* what) {
+    if (rc == 0) return LCF_OK;
+    return fail(LCF_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+struct lcf_comm {
+    void* comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+lcf_status lcf_comm_unique_id(const char* rccl_path, lcf_comm_id* out) {
+    if (!out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (lcf_status st = rccl_load(rccl_path)) return st;
+    return rccl_check(g_rccl.GetUniqueId(out), "ncclGetUniqueId");
+}
+
+lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t n_ranks, int32_t rank, int32_t device,
+                           lcf_comm** out) {
+    if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = nullptr;
+    if (lcf_status st = rccl_load(rccl_path)) return st;
+    LCF_HIP(hipSetDevice(device));
+    auto* c = new lcf_comm();
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    if (lcf_status st = rccl_check(g_rccl.CommInitRank(&c->comm, n_ranks, *id, rank), "ncclCommInitRank")) {
+        delete c;
+        return st;
+    }
+    *out = c;
+    return LCF_OK;
+}
+
+void lcf_comm_destroy(lcf_comm* c) {
+    if (!c) return;
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+// Whole sharded run enqueued natively: per half-step  k_step (replicated commit + proposals, thermal states of the
+// shard) -> k_points + k_finalize on the shard -> in-place ncclAllGather of the new log-posteriors.  No host
+// round-trip and no Python between half-steps; every rank must call it with the same arguments.
+lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_step, int64_t n_steps,
+                                   int32_t split_mode, const int32_t* perm, int32_t store_chain) {
+    if (!s || !c) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    const int nh = s->ds.n_half;
+    if (nh % c->n_ranks) return fail(LCF_ERR_INVALID_ARGUMENT, "n_walkers / 2 must be divisible by the number of ranks");
+    if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
+    hipStream_t st = s->e->stream;
+    const int width = nh / c->n_ranks, lo = c->rank * width, hi = lo + width;
+    s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
+    LCF_HIP(hipEventRecord(s->ev0, st));
+    for (int64_t k = 0; k < 2 * n_steps; ++k) {
+        if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
+        if (lcf_status r = launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st)) return r;
+        double* buf = s->ds.newlp[(s->g_next - 1) & 1];
+        if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo, buf, (size_t)width, /*ncclDouble*/ 8, c->comm, st),
+                                      "ncclAllGather"))
+            return r;
+    }
+    if (lcf_status r = flush_pending(s, st)) return r;
+    LCF_HIP(hipEventRecord(s->ev1, st));
+    return lcf_sampler_wait(s);
 }
 
 // Enqueue a whole run on the engine's stream and return: several samplers (one engine each = one transient of a

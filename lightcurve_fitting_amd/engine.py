@@ -95,6 +95,10 @@ SIGNATURES = [
     ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
+    ('lcf_comm_unique_id', C.c_int, [C.c_char_p, C.c_void_p]),
+    ('lcf_comm_create', C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('lcf_comm_destroy', None, [C.c_void_p]),
+    ('lcf_sampler_run_sharded', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_sed_destroy', None, [C.c_void_p]),
     ('lcf_sed_set_observations', C.c_int, [C.c_void_p, C.c_int64, _ip, _ip, _dp, _dp]),
@@ -326,6 +330,13 @@ class NativeSampler:
     def wait(self):
         _check(self._lib.lcf_sampler_wait(self._h))
 
+    def run_sharded(self, comm, first_step, nsteps, split='random', store=True):
+        """Collective: the whole run natively over ``comm`` (a :class:`NativeComm`)."""
+        mode, keep, pp = self._split(split, nsteps, self.nwalkers)
+        _check(self._lib.lcf_sampler_run_sharded(self._h, comm._h, int(first_step), int(nsteps), mode, pp,
+                                                 int(bool(store))))
+        self._last = (int(nsteps), bool(store))
+
     def begin(self, first_step, nsteps, split='random', store=True):
         mode, keep, pp = self._split(split, nsteps, self.nwalkers)
         _check(self._lib.lcf_sampler_begin(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
@@ -363,6 +374,42 @@ class NativeSampler:
 
     def last_run_ms(self):
         return float(self._lib.lcf_sampler_last_run_ms(self._h))
+
+
+def rccl_library_path():
+    """The librccl.so PyTorch ships (so that one RCCL serves torch.distributed and the native loop), or ''."""
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        return cand if os.path.exists(cand) else ''
+    except ImportError:
+        return ''
+
+
+class NativeComm:
+    """An RCCL communicator owned by the native library, bootstrapped over an initialised torch.distributed group
+    (the 128-byte unique id is broadcast from rank 0)."""
+
+    def __init__(self, device, group=None):
+        import torch.distributed as dist
+        self._lib = load_library()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        path = rccl_library_path().encode()
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            _check(self._lib.lcf_comm_unique_id(path, uid))
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = C.create_string_buffer(box[0], 128)
+        self._h = C.c_void_p()
+        _check(self._lib.lcf_comm_create(path, uid, self.world, self.rank, int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._lib.lcf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
 
 
 class SedEngine:

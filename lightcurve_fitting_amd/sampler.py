@@ -207,7 +207,7 @@ class EnsembleSampler:
     """
 
     def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None,
-                 force_sharded=False):
+                 force_sharded=False, native_collectives=True):
         from .engine import NativeSampler
         if nwalkers % 2 or nwalkers < 2 * ndim:
             raise ValueError('nwalkers must be even and at least 2 * ndim (emcee requirement)')
@@ -220,11 +220,41 @@ class EnsembleSampler:
         self._native = NativeSampler(engine, nwalkers, seed, a)
         self._group = group
         self._force_sharded = force_sharded  # run the phase-by-phase collective path even with a single rank
+        self.native_collectives = native_collectives
+        self._comm = None  # NativeComm once created, False if unavailable
         self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
         self._chain = np.empty((0, nwalkers, ndim))
         self._lp = np.empty((0, nwalkers))
         self._naccepted = np.zeros(nwalkers, dtype=np.int64)
         self._state = None
+
+    def _native_comm(self):
+        """RCCL communicator for the native sharded loop, or None (then the Python-driven loop over
+        torch.distributed collectives is used): needs equal shards and a loadable RCCL.  Every rank takes the same
+        decision: the outcome of the (collective) creation is agreed with an all-reduce."""
+        if self._comm is False:
+            return None
+        if self._comm is None:
+            import torch
+            import torch.distributed as dist
+            from .engine import NativeComm
+            world = dist.get_world_size(self._group)
+            ok = self.native_collectives and (self.nwalkers // 2) % world == 0
+            comm = None
+            if ok:
+                try:
+                    comm = NativeComm(self.engine.device, self._group)
+                except Exception:  # noqa: BLE001 - any failure means: use the torch.distributed path
+                    comm = None
+            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+            flag = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+            self._comm = comm if comm is not None else False
+        return self._comm or None
 
     def _distributed(self):
         try:
@@ -266,7 +296,9 @@ class EnsembleSampler:
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         self._in_flight = False
         try:
-            if self._distributed():
+            if self._distributed() and self._native_comm() is not None:
+                self._native.run_sharded(self._comm, self._steps_done, nsteps, split, store)
+            elif self._distributed():
                 ShardedStretchDriver(NativeBackend(self._native), self._group,
                                      force_collective=self._force_sharded).run(self._steps_done, nsteps, split, store)
             elif asynchronous:

@@ -130,9 +130,10 @@ def test_lightcurve_mcmc_end_to_end():
     assert s2.chain.shape == (32, 10, 6) and m2.input_names[-1] == '\\sigma'
 
 
-def test_collective_path_single_rank_nccl():
-    """The multi-GPU code path (torch.distributed over RCCL, device buffers aliased into torch, all-gather of the new
-    log-probabilities) with one rank: must reproduce the fused native run bit for bit."""
+def test_collective_paths_single_rank_rccl():
+    """Both multi-GPU code paths with one rank -- (i) the native loop with its own RCCL communicator (dlopen'd,
+    bootstrapped over torch.distributed) and (ii) the Python-driven loop over torch.distributed collectives on the
+    aliased device buffer -- must reproduce the fused single-GPU run bit for bit."""
     import os
     import socket
     import torch
@@ -148,13 +149,22 @@ def test_collective_path_single_rank_nccl():
     try:
         a = EnsembleSampler(32, 5, eng, seed=4242, force_sharded=True)
         a.run_mcmc(x0, 8)
+        a.run_mcmc(None, 4)
+        assert a._comm not in (None, False), 'the native RCCL communicator was not created'
+        c = EnsembleSampler(32, 5, eng, seed=4242, force_sharded=True, native_collectives=False)
+        c.run_mcmc(x0, 8)
+        c.run_mcmc(None, 4)
+        assert c._comm is False
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
     b = EnsembleSampler(32, 5, eng, seed=4242)
     b.run_mcmc(x0, 8)
-    assert np.array_equal(a.get_chain(), b.get_chain())
-    assert np.array_equal(a.get_log_prob(), b.get_log_prob())
+    b.run_mcmc(None, 4)
+    for s in (a, c):
+        assert np.array_equal(s.get_chain(), b.get_chain())
+        assert np.array_equal(s.get_log_prob(), b.get_log_prob())
+        assert np.array_equal(s.acceptance_fraction, b.acceptance_fraction)
 
 
 def test_population_mode_equals_individual_runs():
