@@ -294,21 +294,22 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
     walker_coefficients(pb, p, lq, c);
 }
 
+// One parameter's log-prior term; -inf outside the strict bounds.  models.py:1055-1098
+__device__ inline double prior_term(const PriorDev& pr, double x) {
+    if (!(pr.p_min < x && x < pr.p_max)) return -INFINITY;
+    if (pr.kind == 1) return -log(x);
+    if (pr.kind == 2) {
+        const double u = (x - pr.mean) / pr.stddev;
+        return -0.5 * u * u;
+    }
+    return 0.;
+}
+
 // log-prior of one walker; -inf outside the strict bounds.  models.py:1055-1098, fitting.py:122-126
 __device__ inline double walker_log_prior(const DevProblem& pb, const double* __restrict__ p) {
     if (!pb.has_priors) return 0.;
-    double lp = 0.;
-    for (int i = 0; i < pb.n_dim; ++i) {
-        const PriorDev pr = pb.priors[i];
-        const double x = p[i];
-        if (!(pr.p_min < x && x < pr.p_max)) return -INFINITY;
-        if (pr.kind == 1) {
-            lp -= log(x);
-        } else if (pr.kind == 2) {
-            const double u = (x - pr.mean) / pr.stddev;
-            lp -= 0.5 * u * u;
-        }
-    }
+    double lp = 0.;  // same ordered sum of the same terms as the lane-parallel form in k_step
+    for (int i = 0; i < pb.n_dim; ++i) lp += prior_term(pb.priors[i], p[i]);
     return lp;
 }
 

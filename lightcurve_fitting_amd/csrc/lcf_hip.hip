@@ -261,17 +261,14 @@ struct SlotRec {
     double lp_old;  // log-posterior of the walker when the proposal was drawn
     double lpri;    // log-prior of the proposal
 };
-// Per walker: its latest proposal among the half-steps of one parity (one 16-byte load).
-struct LastRec {
-    long long g;  // half-step (-1: none)
-    int slot, pad;
-};
 // Per (step, half, slot): the state-independent part of the stretch move, drawn for the whole run in advance.
 struct DrawRec {
-    int wid, pid;  // active walker and its partner from the complementary colour
-    double z;      // stretch factor
-    double zl;     // (n_dim - 1) ln z
-    double lnu;    // ln u
+    int wid, pid;      // active walker and its partner from the complementary colour
+    int wprev, pprev;  // their proposal slots in the previous half-step of the run (-1: not active there)
+    double z;          // stretch factor
+    double zl;         // (n_dim - 1) ln z
+    double lnu;        // ln u
+    double pad;
 };
 
 struct DevSampler {
@@ -285,8 +282,6 @@ struct DevSampler {
     double* Q[2];       // [n_half][n_dim]     proposals
     SlotRec* rec[2];    // [n_half]
     double* newlp[2];   // [n_half]            log-posterior of the proposal (finalize kernel / all-gather)
-    int* act[2];        // [n_half]            walker id of each slot
-    LastRec* last[2];   // [n_walkers]
     const double* part; // [n_half][n_parts]   chi^2 partial sums of the latest evaluation
     double* chain;      // [n_steps][n_walkers][n_dim]
     double* chain_lp;   // [n_steps][n_walkers]
@@ -343,9 +338,22 @@ __device__ inline double finalize_one(const DevProblem& pb, const double* __rest
     return lp - 0.5 * s;
 }
 
+// Slot of every walker in each half-step of the run (-1 where it is not active): slot_of[row][half][walker].
+__global__ void k_slots(int n_walkers, int n_half, const int* __restrict__ perm, long long n_steps,
+                        int* __restrict__ slot_of) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_steps * n_walkers) return;
+    const long long row = idx / n_walkers;
+    const int pos = (int)(idx % n_walkers);  // position in the permutation: colour 0 = first n_half entries
+    const int wid = perm ? perm[idx] : pos;
+    const int half = pos < n_half ? 0 : 1, slot = pos < n_half ? pos : pos - n_half;
+    slot_of[((size_t)row * 2 + half) * n_walkers + wid] = slot;
+    slot_of[((size_t)row * 2 + (1 - half)) * n_walkers + wid] = -1;
+}
+
 // The state-independent half of every stretch move of a run, one thread per (step, half, slot).
-__global__ void k_draws(DevSampler sm, const int* __restrict__ perm, long long first_step, long long n_steps,
-                        DrawRec* __restrict__ draws) {
+__global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* __restrict__ slot_of,
+                        long long first_step, long long n_steps, DrawRec* __restrict__ draws) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_steps * 2 * sm.n_half) return;
     const int i = (int)(idx % sm.n_half), half = (int)((idx / sm.n_half) & 1);
@@ -365,9 +373,13 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, long long f
     DrawRec d;
     d.wid = wid;
     d.pid = pr ? pr[other_slot] : other_slot;
+    const long long hprev = row * 2 + half - 1;  // previous half-step of the run
+    d.wprev = hprev >= 0 ? slot_of[(size_t)hprev * sm.n_walkers + d.wid] : -1;
+    d.pprev = hprev >= 0 ? slot_of[(size_t)hprev * sm.n_walkers + d.pid] : -1;
     d.z = z;
     d.zl = (double)(sm.n_dim - 1) * log(z);
     d.lnu = log(u01(s2[0], s2[1]));
+    d.pad = 0.;
     draws[idx] = d;
 }
 
@@ -380,7 +392,8 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, long long f
 // threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
 __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
                                                  long long prev_row, int have_next,
-                                                 const DrawRec* __restrict__ draws, long long g, int lo, int hi,
+                                                 const DrawRec* __restrict__ draws,
+                                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
                                                  int n_echunks, int do_thermal, double* __restrict__ coef,
                                                  double* __restrict__ lprior, double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
@@ -390,19 +403,21 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
     const int lane = threadIdx.x;
     const int ep = ec * kBlock + lane;
     const double t_ep = (in_shard && ep < pb.n_epochs) ? pb.epoch_t[ep] : 0.;  // issued before the serial section
+    const int prev_wid = (have_prev && ec == 0) ? prev_draws[i].wid : 0;
+    PriorDev my_prior{0, 0, 0., 0., 0., 1.};
+    if (lane < pb.n_dim && pb.has_priors && have_next) my_prior = pb.priors[lane];
     if (lane < 64) {
         const int pp = (int)((g - 1) & 1), cp = (int)(g & 1), nd = sm.n_dim;
-        DrawRec dr{0, 0, 1., 0., 0.};
+        DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
         if (have_next) dr = draws[i];
         // --- roles: which accept test (if any) this lane evaluates ---
         int rw = -1, rslot = -1;
         if (lane == 0 && have_prev && ec == 0) {
             rslot = i;
-            rw = sm.act[pp][i];
+            rw = prev_wid;  // walker of slot i in the previous half-step (from its draw record)
         } else if ((lane == 1 || lane == 2) && have_next) {
             rw = lane == 1 ? dr.wid : dr.pid;
-            const LastRec lr = sm.last[pp][rw];
-            if (lr.g == g - 1) rslot = lr.slot;
+            rslot = have_prev ? (lane == 1 ? dr.wprev : dr.pprev) : -1;
         }
         double row[kMaxDim], qrow[kMaxDim], lp_cur = 0., nlp = 0.;
         bool ok = false;
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
             if (ok) {
                 for (int d = 0; d < nd; ++d) sm.X[(size_t)rw * nd + d] = row[d];
                 sm.LP[rw] = nlp;
-                sm.nacc[rw] += 1;
+                atomicAdd((unsigned long long*)&sm.nacc[rw], 1ull);
             }
             if (sm.store_chain) {
                 double* crow = sm.chain + ((size_t)prev_row * sm.n_walkers + rw) * nd;
@@ -455,15 +470,20 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
             for (int d = 0; d < kMaxDim; ++d) lq[d] = __shfl(lg, d, 64);
             double c[kNCoef];
             walker_coefficients(pb, q, lq, c);
-            const double lpr = walker_log_prior(pb, q);
+            // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
+            double lpr = 0.;
+            if (pb.has_priors) {
+                double mine = 0.;
+                for (int d = 0; d < kMaxDim; ++d)
+                    if (lane == d && d < pb.n_dim) mine = prior_term(my_prior, q[d]);
+                for (int d = 0; d < pb.n_dim; ++d) lpr += __shfl(mine, d, 64);
+            }
             if (lane == 0) {
                 for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
                 sc[kNCoef] = lpr;
                 if (ec == 0) {  // publish the per-slot records
                     for (int d = 0; d < nd; ++d) sm.Q[cp][(size_t)i * nd + d] = q[d];
-                    sm.act[cp][i] = dr.wid;
                     sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
-                    sm.last[cp][dr.wid] = LastRec{g, i, 0};
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
                     lprior[i] = lpr;
                 }
@@ -1024,11 +1044,12 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
     const long long rel = g - s->g_run0;
     const DrawRec* draws = have_next ? s->d_draws + (size_t)rel * ds.n_half : nullptr;
+    const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
     const bool thermal = have_next && fuse_thermal && e->dp.use_therm;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
     hipLaunchKernelGGL(k_step, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, e->dp, ds,
-                       have_prev, prev_row, have_next ? 1 : 0, draws, g, lo, hi, nec, thermal ? 1 : 0, s->coef,
+                       have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, nec, thermal ? 1 : 0, s->coef,
                        s->lprior, s->therm);
     LCF_HIP(hipGetLastError());
     s->pending = have_next;
@@ -1080,7 +1101,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
     AL(ds.X, nw * nd); AL(ds.LP, nw); AL(ds.nacc, nw); AL(ds.err, 1);
     for (int b = 0; b < 2; ++b) {
-        AL(ds.last[b], nw); AL(ds.Q[b], nh * nd); AL(ds.rec[b], nh); AL(ds.newlp[b], nh); AL(ds.act[b], nh);
+        AL(ds.Q[b], nh * nd); AL(ds.rec[b], nh); AL(ds.newlp[b], nh);
     }
     AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_parts);
     if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
@@ -1088,7 +1109,6 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     ds.part = s->part;
     LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
-    for (int b = 0; b < 2; ++b) LCF_HIP(hipMemset(ds.last[b], 0xff, nw * sizeof(LastRec)));  // g = -1: no proposal yet
     LCF_HIP(hipEventCreate(&s->ev0));
     LCF_HIP(hipEventCreate(&s->ev1));
     *out = s;
@@ -1109,8 +1129,6 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     if (lcf_status st = logprob_dev(e, ds.n_walkers, ds.X, ds.LP, e->stream, 1)) return st;
     LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
-    for (int b = 0; b < 2; ++b)
-        LCF_HIP(hipMemsetAsync(ds.last[b], 0xff, (size_t)ds.n_walkers * sizeof(LastRec), e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));
     s->has_state = true;
     return LCF_OK;
@@ -1205,10 +1223,18 @@ lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps
             s->draw_rows = n_steps;
         }
         const long long total = (long long)n_steps * ds.n_walkers;
-        hipLaunchKernelGGL(k_draws, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds,
-                           s->have_perm ? s->d_perm : nullptr, (long long)first_step, (long long)n_steps, s->d_draws);
-        LCF_HIP(hipGetLastError());
-        LCF_HIP(hipStreamSynchronize(e->stream));
+        int* slot_of = nullptr;  // [n_steps][2][n_walkers], scratch for this call only
+        LCF_HIP(hipMalloc((void**)&slot_of, (size_t)total * 2 * sizeof(int)));
+        const int* dperm = s->have_perm ? s->d_perm : nullptr;
+        hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds.n_walkers,
+                           ds.n_half, dperm, (long long)n_steps, slot_of);
+        hipLaunchKernelGGL(k_draws, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds, dperm, slot_of,
+                           (long long)first_step, (long long)n_steps, s->d_draws);
+        const hipError_t lerr = hipGetLastError();
+        const hipError_t serr = hipStreamSynchronize(e->stream);
+        hipFree(slot_of);
+        LCF_HIP(lerr);
+        LCF_HIP(serr);
     }
     return LCF_OK;
 }
