@@ -212,15 +212,17 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
  * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged
  * blackbody [f.synthesize(planck_fast, T, R) for f in filters].  precision 0 = float64, 1 = float32 arithmetic. */
 typedef struct lcf_sed lcf_sed;
+/* ctab_*: optional Gauss-compressed companions of the band tables (all NULL = none), as in lcf_problem. */
 lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const double* tab_a, const double* tab_w,
-                          int32_t device, lcf_sed** out);
+                          const int32_t* ctab_off, const double* ctab_a, const double* ctab_w,
+                          const double* ctab_tmin, int32_t device, lcf_sed** out);
 void lcf_sed_destroy(lcf_sed* s);
 lcf_status lcf_sed_set_observations(lcf_sed* s, int64_t n_epochs, const int32_t* ep_off, const int32_t* filt_idx,
                                     const double* y, const double* dy);
 /* cand[n_epochs][n_cand][n_par] (n_par = 2 or 3), out[n_epochs][n_cand]; kernel_ms (optional) receives the device
  * time of the kernel alone (HIP events on the engine's stream). */
 lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int32_t sigma_type, const double* cand,
-                                  int32_t precision, double* out, double* kernel_ms);
+                                  int32_t precision, int32_t use_compressed, double* out, double* kernel_ms);
 
 #ifdef __cplusplus
 }

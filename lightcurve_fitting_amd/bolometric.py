@@ -64,7 +64,8 @@ class SpectrumLikelihood:
         uniq = list(dict.fromkeys(f for fl in filts for f in fl))
         lookup = {f: i for i, f in enumerate(uniq)}
         tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
-        self.engine = _eng.SedEngine(tabs.off, tabs.a, tabs.w, device=device)
+        self.engine = _eng.SedEngine(tabs.off, tabs.a, tabs.w, device=device,
+                                     ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
         off = np.concatenate([[0], np.cumsum([len(fl) for fl in filts])])
         idx = np.array([lookup[f] for fl in filts for f in fl], dtype=np.int32)
         y = np.concatenate([np.asarray(e[1], dtype=float) for e in epochs]) if len(epochs) else np.zeros(0)
@@ -74,12 +75,13 @@ class SpectrumLikelihood:
         self.samples_per_candidate = np.array([sum(tabs.off[lookup[f] + 1] - tabs.off[lookup[f]] for f in fl)
                                                for fl in filts])
 
-    def __call__(self, candidates, sigma_type='relative', precision='f64'):
-        """``candidates``: (n_epochs, n_cand, 2|3) of (T, R[, sigma]) -> log-likelihoods (n_epochs, n_cand)."""
+    def __call__(self, candidates, sigma_type='relative', precision='f64', compressed=True):
+        """``candidates``: (n_epochs, n_cand, 2|3) of (T, R[, sigma]) -> log-likelihoods (n_epochs, n_cand).
+        ``compressed``: use the Gauss-compressed band tables where they are valid (same sums to 2e-14)."""
         if sigma_type not in ('relative', 'absolute'):
             raise Exception('sigma_type must either be "relative" or "absolute"')
         st = _eng.SIGMA_RELATIVE if sigma_type == 'relative' else _eng.SIGMA_ABSOLUTE
-        return self.engine.log_likelihood(candidates, st, {'f64': 0, 'f32': 1}[precision])
+        return self.engine.log_likelihood(candidates, st, {'f64': 0, 'f32': 1}[precision], compressed)
 
 
 def spectrum_log_likelihood(filters, y, dy, T, R, z=0., sigma=None, sigma_type='relative', precision='f64'):

@@ -26,9 +26,10 @@ constexpr int kSedLdsMax = 3500;  // samples staged in LDS (56 KiB as double2)
 
 struct SedDev {
     int n_filters, n_tab, tab_in_lds, pad;
-    const double2* tab;    // (a, W) float64, padded to quads
+    const double2* tab;    // (a, W) float64: per filter [full | Gauss-compressed], each padded to quads
     const float2* tab32;   // same in float32
-    const int* tab_off;    // [n_filters + 1] (padded offsets)
+    const int4* desc;      // [n_filters] (full offset, full count, compressed offset, compressed count)
+    const double* inv_tmin; // [n_filters] 1 / t_min of the compressed table (0: none)
     const double* exp2tab; // 2^(j/256)
 };
 
@@ -43,7 +44,7 @@ struct SedObs {
 
 template <int PREC>
 __global__ __launch_bounds__(kSedBlock) void k_sed(const SedDev sd, const SedObs ob, long long n_cand, int n_par,
-                                                   int sigma_abs, const double* __restrict__ cand,
+                                                   int sigma_abs, int use_ctab, const double* __restrict__ cand,
                                                    double* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(kSedBlock) void k_sed(const SedDev sd, const SedObs
         double acc = 0.;
         for (int o = o0; o < o1; ++o) {
             const int f = ob.filt[o];
-            const int off = sd.tab_off[f], cnt = sd.tab_off[f + 1] - off;
+            const int4 ds = sd.desc[f];
+            const bool comp = use_ctab && invT <= sd.inv_tmin[f];
+            const int off = comp ? ds.z : ds.x, cnt = comp ? ds.w : ds.y;
             double S = 0.;
             if (hot) {
                 S = sd.tab_in_lds ? band_sum_fast(reinterpret_cast<const double2*>(tabmem) + off, cnt, invT, et)
@@ -103,15 +106,22 @@ __global__ __launch_bounds__(kSedBlock) void k_sed(const SedDev sd, const SedObs
         float acc = 0.f;
         for (int o = o0; o < o1; ++o) {
             const int f = ob.filt[o];
-            const int off = sd.tab_off[f], cnt = sd.tab_off[f + 1] - off;
+            const int4 ds = sd.desc[f];
+            const bool comp = use_ctab && (double)invT <= sd.inv_tmin[f];
+            const int off = comp ? ds.z : ds.x, cnt = comp ? ds.w : ds.y;
             float S = 0.f;
             if (hot) {
                 const float2* tb = sd.tab_in_lds ? lt + off : sd.tab32 + off;
-                for (int k = 0; k < cnt; ++k) {
-                    const float2 aw = tb[k];
-                    const float e = __expf(aw.x * invT);  // v_exp_f32; +inf beyond x ~ 88.7 -> term 0
-                    S += aw.y * __frcp_rn(e - 1.f);
+                const float s2 = invT * 1.4426950408889634f;  // exp(x) = 2^(x log2 e): one v_exp_f32 per sample
+                float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
+                for (int k = 0; k < cnt; k += 4) {  // tables are padded to quads with zero weights
+                    const float2 a0 = tb[k], a1 = tb[k + 1], a2 = tb[k + 2], a3 = tb[k + 3];
+                    S0 = fmaf(a0.y, __frcp_rn(exp2f(a0.x * s2) - 1.f), S0);  // +inf beyond x ~ 88.7 -> term 0
+                    S1 = fmaf(a1.y, __frcp_rn(exp2f(a1.x * s2) - 1.f), S1);
+                    S2 = fmaf(a2.y, __frcp_rn(exp2f(a2.x * s2) - 1.f), S2);
+                    S3 = fmaf(a3.y, __frcp_rn(exp2f(a3.x * s2) - 1.f), S3);
                 }
+                S = (S0 + S1) + (S2 + S3);
             }
             const float yfit = R * R * S;
             const float dy = (float)ob.dy[o];
@@ -135,7 +145,7 @@ struct lcf_sed {
     SedDev sd{};
     SedObs ob{};
     std::vector<void*> owned, obs_owned;
-    std::vector<int> tab_off_host;
+    bool have_ctab = false;
     hipStream_t stream = nullptr;
     double *dcand = nullptr, *dout = nullptr;
     size_t cand_cap = 0, out_cap = 0;
@@ -159,13 +169,18 @@ struct lcf_sed {
 extern "C" {
 
 lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const double* tab_a, const double* tab_w,
-                          int32_t device, lcf_sed** out) {
+                          const int32_t* ctab_off, const double* ctab_a, const double* ctab_w,
+                          const double* ctab_tmin, int32_t device, lcf_sed** out) {
     if (!out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (n_filters <= 0 || !tab_off || !tab_a || !tab_w || tab_off[0] != 0)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad band tables");
-    for (int f = 0; f < n_filters; ++f)
+    const bool have_ctab = ctab_off && ctab_a && ctab_w && ctab_tmin;
+    for (int f = 0; f < n_filters; ++f) {
         if (tab_off[f + 1] < tab_off[f]) return fail(LCF_ERR_INVALID_ARGUMENT, "tab_off must be non-decreasing");
+        if (have_ctab && (ctab_off[f + 1] < ctab_off[f] || ctab_off[0] != 0))
+            return fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off must start at 0 and be non-decreasing");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(LCF_ERR_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
@@ -173,16 +188,28 @@ lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const doubl
     LCF_HIP(hipSetDevice(device));
     std::vector<double2> htab;
     std::vector<float2> htab32;
-    std::vector<int> poff(n_filters + 1, 0);
-    for (int f = 0; f < n_filters; ++f) {
-        for (int k = tab_off[f]; k < tab_off[f + 1]; ++k) {
-            if (!(tab_a[k] > 0.) || !std::isfinite(tab_a[k]) || !std::isfinite(tab_w[k]))
-                return fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0 and finite W_k");
-            htab.push_back(make_double2(tab_a[k], tab_w[k]));
+    std::vector<int4> hdesc(n_filters);
+    std::vector<double> hinvt(n_filters, 0.);
+    auto append = [&](const double* a, const double* w, int k0, int k1, int& off, int& cnt) -> bool {
+        off = (int)htab.size();
+        for (int k = k0; k < k1; ++k) {
+            if (!(a[k] > 0.) || !std::isfinite(a[k]) || !std::isfinite(w[k])) return false;
+            htab.push_back(make_double2(a[k], w[k]));
         }
-        const double apad = tab_off[f + 1] > tab_off[f] ? tab_a[tab_off[f + 1] - 1] : 1.;
-        while ((htab.size() - poff[f]) % 4) htab.push_back(make_double2(apad, 0.));
-        poff[f + 1] = (int)htab.size();
+        const double apad = k1 > k0 ? a[k1 - 1] : 1.;
+        while ((htab.size() - off) % 4) htab.push_back(make_double2(apad, 0.));
+        cnt = (int)htab.size() - off;
+        return true;
+    };
+    for (int f = 0; f < n_filters; ++f) {
+        int4 d = make_int4(0, 0, 0, 0);
+        bool ok = append(tab_a, tab_w, tab_off[f], tab_off[f + 1], d.x, d.y);
+        if (ok && have_ctab && ctab_off[f + 1] > ctab_off[f]) {
+            ok = append(ctab_a, ctab_w, ctab_off[f], ctab_off[f + 1], d.z, d.w) && ctab_tmin[f] >= 0.;
+            hinvt[f] = 1. / ctab_tmin[f];
+        }
+        if (!ok) return fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0, finite W_k, t_min >= 0");
+        hdesc[f] = d;
     }
     if (htab.empty()) htab.push_back(make_double2(1., 0.));
     for (const double2& v : htab) htab32.push_back(make_float2((float)v.x, (float)v.y));
@@ -190,16 +217,16 @@ lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const doubl
     for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
     auto* s = new lcf_sed();
     s->device = device;
-    s->tab_off_host = poff;
+    s->have_ctab = have_ctab;
     lcf_status st;
     double2* dtab;
     float2* dtab32;
-    int* doff;
-    double* dexp;
+    int4* ddesc;
+    double *dexp, *dinvt;
 #define UP(h, d) if ((st = upload(h, &d, s->owned)) != LCF_OK) { delete s; return st; }
-    UP(htab, dtab); UP(htab32, dtab32); UP(poff, doff); UP(hexp, dexp);
+    UP(htab, dtab); UP(htab32, dtab32); UP(hdesc, ddesc); UP(hexp, dexp); UP(hinvt, dinvt);
 #undef UP
-    s->sd = SedDev{n_filters, (int)htab.size(), (int)htab.size() <= kSedLdsMax, 0, dtab, dtab32, doff, dexp};
+    s->sd = SedDev{n_filters, (int)htab.size(), (int)htab.size() <= kSedLdsMax, 0, dtab, dtab32, ddesc, dinvt, dexp};
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         delete s;
         return fail(LCF_ERR_HIP, "hipStreamCreate failed");
@@ -244,7 +271,7 @@ lcf_status lcf_sed_set_observations(lcf_sed* s, int64_t n_epochs, const int32_t*
 }
 
 lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int32_t sigma_type, const double* cand,
-                                  int32_t precision, double* out, double* kernel_ms) {
+                                  int32_t precision, int32_t use_compressed, double* out, double* kernel_ms) {
     if (!s || n_cand < 0 || (n_cand > 0 && (!cand || !out))) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     if (n_par != 2 && n_par != 3) return fail(LCF_ERR_INVALID_ARGUMENT, "n_par must be 2 (T, R) or 3 (T, R, sigma)");
     if (precision != 0 && precision != 1) return fail(LCF_ERR_INVALID_ARGUMENT, "precision must be 0 (f64) or 1 (f32)");
@@ -270,6 +297,7 @@ lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int
         s->out_cap = no;
     }
     LCF_HIP(hipMemcpyAsync(s->dcand, cand, nc * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    const int uc = (use_compressed && s->have_ctab) ? 1 : 0;
     const long long tiles = (n_cand + kSedBlock - 1) / kSedBlock;
     const dim3 grid((unsigned)(ne * tiles));
     const size_t lds = kExpTabSize * sizeof(double) +
@@ -282,10 +310,10 @@ lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int
     }
     if (precision == 0)
         hipLaunchKernelGGL(k_sed<0>, grid, dim3(kSedBlock), lds, s->stream, s->sd, s->ob, (long long)n_cand, n_par,
-                           sigma_type == LCF_SIGMA_ABSOLUTE, s->dcand, s->dout);
+                           sigma_type == LCF_SIGMA_ABSOLUTE, uc, s->dcand, s->dout);
     else
         hipLaunchKernelGGL(k_sed<1>, grid, dim3(kSedBlock), lds, s->stream, s->sd, s->ob, (long long)n_cand, n_par,
-                           sigma_type == LCF_SIGMA_ABSOLUTE, s->dcand, s->dout);
+                           sigma_type == LCF_SIGMA_ABSOLUTE, uc, s->dcand, s->dout);
     LCF_HIP(hipGetLastError());
     if (kernel_ms) LCF_HIP(hipEventRecord(b, s->stream));
     LCF_HIP(hipMemcpyAsync(out, s->dout, no * sizeof(double), hipMemcpyDeviceToHost, s->stream));

@@ -99,10 +99,11 @@ SIGNATURES = [
     ('lcf_comm_create', C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_comm_destroy', None, [C.c_void_p]),
     ('lcf_sampler_run_sharded', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
-    ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_sed_destroy', None, [C.c_void_p]),
     ('lcf_sed_set_observations', C.c_int, [C.c_void_p, C.c_int64, _ip, _ip, _dp, _dp]),
-    ('lcf_sed_log_likelihood', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp]),
+    ('lcf_sed_log_likelihood', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, _dp,
+                                         _dp]),
 ]
 
 
@@ -416,11 +417,17 @@ class SedEngine:
     """Per-epoch blackbody SED likelihood on the device (``lcf_sed_*``): band tables are fixed at creation,
     observations are set per batch of epochs, candidates are evaluated per call."""
 
-    def __init__(self, tab_off, tab_a, tab_w, device=0):
+    def __init__(self, tab_off, tab_a, tab_w, device=0, ctab=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         off, a, w = _i32(tab_off), _f64(tab_a), _f64(tab_w)
-        _check(self._lib.lcf_sed_create(len(off) - 1, _ptr(off, _ip), _ptr(a), _ptr(w), int(device), C.byref(self._h)))
+        if ctab is None:
+            cargs = (None, None, None, None)
+        else:
+            cx = [_i32(ctab[0]), _f64(ctab[1]), _f64(ctab[2]), _f64(ctab[3])]
+            cargs = (_ptr(cx[0], _ip), _ptr(cx[1]), _ptr(cx[2]), _ptr(cx[3]))
+        _check(self._lib.lcf_sed_create(len(off) - 1, _ptr(off, _ip), _ptr(a), _ptr(w), *cargs, int(device),
+                                        C.byref(self._h)))
         self.n_epochs = 0
         self.last_kernel_ms = 0.
 
@@ -438,7 +445,7 @@ class SedEngine:
         _check(self._lib.lcf_sed_set_observations(self._h, len(off) - 1, _ptr(off, _ip), _ptr(f, _ip), _ptr(y), _ptr(dy)))
         self.n_epochs = len(off) - 1
 
-    def log_likelihood(self, cand, sigma_type=SIGMA_RELATIVE, precision=0):
+    def log_likelihood(self, cand, sigma_type=SIGMA_RELATIVE, precision=0, compressed=True):
         """``cand``: (n_epochs, n_cand, 2 or 3) -> (n_epochs, n_cand)."""
         cand = _f64(cand)
         if cand.ndim != 3 or cand.shape[0] != self.n_epochs or cand.shape[2] not in (2, 3):
@@ -446,6 +453,6 @@ class SedEngine:
         out = np.empty(cand.shape[:2])
         ms = C.c_double()
         _check(self._lib.lcf_sed_log_likelihood(self._h, cand.shape[1], cand.shape[2], int(sigma_type), _ptr(cand),
-                                                int(precision), _ptr(out), C.byref(ms)))
+                                                int(precision), int(bool(compressed)), _ptr(out), C.byref(ms)))
         self.last_kernel_ms = ms.value
         return out

@@ -20,9 +20,10 @@ def test_sed_float64_parity():
     g = golden('sed')
     like = B.SpectrumLikelihood(_epochs(g), z=float(g['sed/z']))
     c = g['sed/cand']
-    assert relerr(like(c[:, :, :2]), g['sed/ll']) < 1e-11
-    assert relerr(like(c, 'relative'), g['sed/ll_rel']) < 1e-11
-    assert relerr(like(c, 'absolute'), g['sed/ll_abs']) < 1e-11
+    for comp in (True, False):  # Gauss-compressed and full band tables
+        assert relerr(like(c[:, :, :2], compressed=comp), g['sed/ll']) < 1e-11
+        assert relerr(like(c, 'relative', compressed=comp), g['sed/ll_rel']) < 1e-11
+        assert relerr(like(c, 'absolute', compressed=comp), g['sed/ll_abs']) < 1e-11
     with pytest.raises(Exception, match='sigma_type'):
         like(c, 'bogus')
     with pytest.raises(ValueError, match='shape'):
