@@ -170,6 +170,10 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
 lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                                  const int32_t* perm, int32_t store_chain);
 lcf_status lcf_sampler_wait(lcf_sampler* s);
+/* Population mode: run n samplers (independent transients with the same walker count, on one device) in lock step:
+ * one proposal launch and one likelihood launch per half-step cover all of them.  split_mode: identity or random. */
+lcf_status lcf_population_run(lcf_sampler** samplers, int32_t n, int64_t first_step, int64_t n_steps,
+                              int32_t split_mode, int32_t store_chain, double* elapsed_ms);
 /* Chain of the last run: chain[n_steps][n_walkers][n_dim], log_prob[n_steps][n_walkers] (either may be NULL). */
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob);
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);

@@ -114,18 +114,17 @@ __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_l
 // that every workgroup sees a similar mix of filters) with the exp table and ALL band tables staged in LDS once, and
 // reduces once at the end.
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
-__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
-                                                   const double* __restrict__ coef,
-                                                   const double* __restrict__ lprior,
-                                                   const double2* __restrict__ therm, double* __restrict__ out0,
-                                                   double* __restrict__ out1) {
+__device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int n_w, const double* __restrict__ P,
+                                   const double* __restrict__ coef, const double* __restrict__ lprior,
+                                   const double2* __restrict__ therm, double* __restrict__ out0,
+                                   double* __restrict__ out1) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
     double* red = exptab + kExpTabSize;                                   // 4 doubles
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
 
-    const int part = blockIdx.x / n_w;
-    const int w = w_lo + blockIdx.x % n_w;
+    const int part = bid / n_w;
+    const int w = w_lo + bid % n_w;
     const int tid = threadIdx.x;
 
     if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
@@ -206,6 +205,15 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
         __syncthreads();
         if (tid == 0) out0[(size_t)w * pb.n_parts + part] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+}
+
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
+__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
+                                                   const double* __restrict__ coef,
+                                                   const double* __restrict__ lprior,
+                                                   const double2* __restrict__ therm, double* __restrict__ out0,
+                                                   double* __restrict__ out1) {
+    points_body<VARIANT, MODE, LDS_TAB, THERM>(pb, blockIdx.x, w_lo, n_w, P, coef, lprior, therm, out0, out1);
 }
 
 // lnL (and log-posterior) per walker from the partial sums, fixed summation order.
@@ -390,14 +398,13 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
 //   on the outcome issued up front (both candidate rows included);  lanes 0..n_par-1: ln of the proposal's parameters.
 // Every lane ends with the same proposal (bitwise); lane 0 of the chunk-0 workgroup publishes it.  Then all 256
 // threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
-__global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
-                                                 long long prev_row, int have_next,
-                                                 const DrawRec* __restrict__ draws,
-                                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
-                                                 int n_echunks, int do_thermal, double* __restrict__ coef,
-                                                 double* __restrict__ lprior, double2* __restrict__ therm) {
+__device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int bid, int have_prev,
+                                 long long prev_row, int have_next, const DrawRec* __restrict__ draws,
+                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi, int n_echunks,
+                                 int do_thermal, double* __restrict__ coef, double* __restrict__ lprior,
+                                 double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
-    const int i = blockIdx.x / n_echunks, ec = blockIdx.x % n_echunks;
+    const int i = bid / n_echunks, ec = bid % n_echunks;
     const bool in_shard = do_thermal && i >= lo && i < hi;
     if (ec > 0 && !in_shard) return;
     const int lane = threadIdx.x;
@@ -497,6 +504,48 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
     double T, pref;
     thermal_state(pb, sc, t_ep, T, pref);
     therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
+}
+
+__global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
+                                                 long long prev_row, int have_next,
+                                                 const DrawRec* __restrict__ draws,
+                                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
+                                                 int n_echunks, int do_thermal, double* __restrict__ coef,
+                                                 double* __restrict__ lprior, double2* __restrict__ therm) {
+    step_body(pb, sm, blockIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, lo, hi, n_echunks, do_thermal,
+              coef, lprior, therm);
+}
+
+// ---- population mode: one launch covers the same half-step of MANY independent transients (blockIdx.y) --------------
+struct MultiItem {
+    DevProblem pb;
+    DevSampler sm;
+    const DrawRec* draws;  // [n_steps][2][n_half]
+    double* coef;
+    double* lprior;
+    double2* therm;
+    double* part;
+};
+
+__global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restrict__ items, int have_prev,
+                                                       long long prev_row, int have_next, long long rel,
+                                                       long long g, int thermal) {
+    const MultiItem& it = items[blockIdx.y];
+    const int nh = it.sm.n_half;
+    const int nec = thermal ? (it.pb.n_epochs + kBlock - 1) / kBlock : 1;
+    if ((int)blockIdx.x >= nh * nec) return;
+    step_body(it.pb, it.sm, blockIdx.x, have_prev, prev_row, have_next,
+              have_next ? it.draws + (size_t)rel * nh : nullptr, have_prev ? it.draws + (size_t)(rel - 1) * nh : nullptr,
+              g, 0, nh, nec, thermal, it.coef, it.lprior, it.therm);
+}
+
+template <int VARIANT, bool LDS_TAB, bool THERM>
+__global__ __launch_bounds__(kBlock) void k_points_multi(const MultiItem* __restrict__ items, int parity) {
+    const MultiItem& it = items[blockIdx.y];
+    const int nh = it.sm.n_half;
+    if ((int)blockIdx.x >= nh * it.pb.n_parts) return;
+    points_body<VARIANT, 0, LDS_TAB, THERM>(it.pb, blockIdx.x, 0, nh, it.sm.Q[parity], it.coef, it.lprior, it.therm,
+                                            it.part, nullptr);
 }
 
 }  // namespace
@@ -1416,6 +1465,88 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
                            const int32_t* perm, int32_t store_chain) {
     if (lcf_status st = lcf_sampler_run_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     return lcf_sampler_wait(s);
+}
+
+// Population mode: the same n_steps for `n` samplers (one transient each, same walker count) with ONE k_step and ONE
+// k_points launch per half-step covering all of them (blockIdx.y = transient).
+lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                              int32_t store_chain, double* elapsed_ms) {
+    if (!ss || n <= 0) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > 65535) return fail(LCF_ERR_INVALID_ARGUMENT, "at most 65535 transients per call");
+    if (split_mode == LCF_SPLIT_HOST) return fail(LCF_ERR_UNSUPPORTED, "population runs use identity or random splits");
+    const lcf_sampler* s0 = ss[0];
+    if (!s0) return fail(LCF_ERR_INVALID_ARGUMENT, "null sampler");
+    for (int t = 0; t < n; ++t) {
+        const lcf_sampler* s = ss[t];
+        if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null sampler");
+        const DevProblem &a = s->e->dp, &b = s0->e->dp;
+        if (s->e->device != s0->e->device || s->ds.n_walkers != s0->ds.n_walkers || a.variant != b.variant ||
+            a.use_therm != b.use_therm || a.tab_in_lds != b.tab_in_lds)
+            return fail(LCF_ERR_UNSUPPORTED, "transients of one batched run must agree on device, walker count, "
+                                             "band-sum variant, thermal sharing and table placement");
+    }
+    long long g = 0;
+    for (int t = 0; t < n; ++t) {
+        if (lcf_status st = lcf_sampler_begin(ss[t], first_step, n_steps, split_mode, nullptr, store_chain)) return st;
+        g = std::max(g, ss[t]->g_next);
+    }
+    std::vector<MultiItem> items(n);
+    size_t lds = 0;
+    int max_nec = 1, max_parts = 1;
+    const bool thermal = s0->e->dp.use_therm != 0;
+    for (int t = 0; t < n; ++t) {
+        lcf_sampler* s = ss[t];
+        s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
+        s->ds.inline_finalize = 1;
+        items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm, s->part};
+        lds = std::max(lds, s->e->lds_bytes);
+        max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
+        max_parts = std::max(max_parts, s->e->dp.n_parts);
+    }
+    LCF_HIP(hipSetDevice(s0->e->device));
+    MultiItem* ditems = nullptr;
+    LCF_HIP(hipMalloc((void**)&ditems, (size_t)n * sizeof(MultiItem)));
+    hipStream_t st = s0->e->stream;
+    hipError_t err = hipMemcpyAsync(ditems, items.data(), (size_t)n * sizeof(MultiItem), hipMemcpyHostToDevice, st);
+    const int nh = s0->ds.n_half;
+    const DevProblem& p0 = s0->e->dp;
+    hipEvent_t ev0 = s0->ev0, ev1 = s0->ev1;
+    if (err == hipSuccess) err = hipEventRecord(ev0, st);
+    const dim3 gs((unsigned)(nh * max_nec), (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
+    const dim3 bs(thermal ? kBlock : 64), bp(kBlock);
+    for (int64_t k = 0; k <= 2 * n_steps && err == hipSuccess; ++k) {
+        const bool have_next = k < 2 * n_steps, have_prev = k > 0;
+        if (!have_next && !have_prev) break;
+        hipLaunchKernelGGL(k_step_multi, have_next ? gs : dim3((unsigned)nh, (unsigned)n), have_next ? bs : dim3(64), 0,
+                           st, ditems, have_prev ? 1 : 0, (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k,
+                           (long long)(g + k), (have_next && thermal) ? 1 : 0);
+        if (!have_next) break;
+        const int parity = (int)((g + k) & 1);
+#define LCF_PM(V, L, T) hipLaunchKernelGGL((k_points_multi<V, L, T>), gp, bp, lds, st, ditems, parity)
+        if (p0.variant == 0) {
+            if (p0.tab_in_lds) { if (thermal) LCF_PM(0, true, true); else LCF_PM(0, true, false); }
+            else { if (thermal) LCF_PM(0, false, true); else LCF_PM(0, false, false); }
+        } else {
+            if (p0.tab_in_lds) { if (thermal) LCF_PM(1, true, true); else LCF_PM(1, true, false); }
+            else { if (thermal) LCF_PM(1, false, true); else LCF_PM(1, false, false); }
+        }
+#undef LCF_PM
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipEventRecord(ev1, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    hipFree(ditems);
+    LCF_HIP(err);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && elapsed_ms) *elapsed_ms = ms;
+    for (int t = 0; t < n; ++t) {
+        ss[t]->g_next = g + 2 * n_steps;
+        ss[t]->pending = false;
+        ss[t]->last_ms = ms;
+    }
+    for (int t = 0; t < n; ++t)
+        if (lcf_status r = lcf_sampler_check(ss[t])) return r;
+    return LCF_OK;
 }
 
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob) {

@@ -85,6 +85,8 @@ SIGNATURES = [
     ('lcf_sampler_run', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sampler_run_async', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sampler_wait', C.c_int, [C.c_void_p]),
+    ('lcf_population_run', C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                     _dp]),
     ('lcf_sampler_get_chain', C.c_int, [C.c_void_p, _dp, _dp]),
     ('lcf_sampler_get_naccepted', C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ('lcf_sampler_last_run_ms', C.c_double, [C.c_void_p]),
@@ -375,6 +377,19 @@ class NativeSampler:
 
     def last_run_ms(self):
         return float(self._lib.lcf_sampler_last_run_ms(self._h))
+
+
+def population_run(native_samplers, first_step, nsteps, split='random', store=True):
+    """One batched native run over several :class:`NativeSampler` objects (population mode).  Returns device ms."""
+    lib = load_library()
+    n = len(native_samplers)
+    arr = (C.c_void_p * n)(*[s._h for s in native_samplers])
+    mode = {'identity': SPLIT_IDENTITY, 'random': SPLIT_RANDOM}[split]
+    ms = C.c_double()
+    _check(lib.lcf_population_run(arr, n, int(first_step), int(nsteps), mode, int(bool(store)), C.byref(ms)))
+    for s in native_samplers:
+        s._last = (int(nsteps), bool(store))
+    return ms.value
 
 
 def rccl_library_path():

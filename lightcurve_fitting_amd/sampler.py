@@ -175,14 +175,32 @@ class PopulationSampler:
             self.samplers[k] = EnsembleSampler(nwalkers, eng.ndim, eng, seed=seed + k, a=a)
         self.nwalkers = nwalkers
 
-    def run_mcmc(self, initial_states, nsteps, store=True):
-        """``initial_states``: mapping/sequence index -> (nwalkers, ndim) coordinates, or None to continue."""
-        started = []
+    def run_mcmc(self, initial_states, nsteps, store=True, batched=True):
+        """``initial_states``: mapping/sequence index -> (nwalkers, ndim) coordinates, or None to continue.
+
+        ``batched`` (default): one native call runs all transients in lock step with one proposal launch and one
+        likelihood launch per half-step for the whole population; if the transients cannot share launches (mixed
+        table placement etc.) or ``batched`` is false, every ensemble is enqueued on its own stream instead."""
+        from .engine import LcfError, population_run
+        samplers = list(self.samplers.values())
         for k, s in self.samplers.items():
-            x0 = None if initial_states is None else initial_states[k]
-            s._start(x0, nsteps, store)
-            started.append(s)
-        for s in started:
+            s._prepare(None if initial_states is None else initial_states[k])
+        done = False
+        if batched and samplers and len({s._steps_done for s in samplers}) == 1 and \
+                len({s.randomize_split for s in samplers}) == 1:
+            try:
+                self.last_run_ms = population_run([s._native for s in samplers], samplers[0]._steps_done, nsteps,
+                                                  'random' if samplers[0].randomize_split else 'identity', store)
+                done = True
+            except LcfError as exc:
+                if exc.status == 6:
+                    raise ValueError('Probability function returned NaN') from None
+                if exc.status != 5:  # LCF_ERR_UNSUPPORTED -> per-transient streams
+                    raise
+        for s in samplers:
+            if not done:
+                s._launch(nsteps, store, asynchronous=True)
+        for s in samplers:
             s._finish(nsteps, store)
         return {k: s._state for k, s in self.samplers.items()}
 
@@ -272,7 +290,8 @@ class EnsembleSampler:
         self._lp = np.empty((0, self.nwalkers))
         self._naccepted[:] = 0
 
-    def _start(self, initial_state, nsteps, store=True, skip_initial_state_check=False, asynchronous=True):
+    def _prepare(self, initial_state, skip_initial_state_check=False):
+        """Validate and upload the starting positions (or continue from the stored state)."""
         if initial_state is not None:
             coords = np.array(initial_state[0] if isinstance(initial_state, tuple) else initial_state,
                               dtype=np.float64)
@@ -291,6 +310,9 @@ class EnsembleSampler:
             self._acc0 = self._native.naccepted()
         if initial_state is not None and np.any(np.isnan(self._native.get_state()[1])):
             raise ValueError('Probability function returned NaN')
+        self._in_flight = False
+
+    def _launch(self, nsteps, store=True, asynchronous=True):
         split = 'random' if self.randomize_split else 'identity'
         if self.randomize_split and self.nwalkers > 16384:  # beyond the device sort: host-generated colouring
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
@@ -333,7 +355,8 @@ class EnsembleSampler:
 
     def run_mcmc(self, initial_state, nsteps, progress=False, progress_kwargs=None, skip_initial_state_check=False,
                  store=True, **kwargs):
-        self._start(initial_state, nsteps, store, skip_initial_state_check, asynchronous=False)
+        self._prepare(initial_state, skip_initial_state_check)
+        self._launch(nsteps, store, asynchronous=False)
         return self._finish(nsteps, store)
 
     def get_chain(self, flat=False, thin=1, discard=0):

@@ -178,14 +178,31 @@ def test_population_mode_equals_individual_runs():
         lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
         problems.append((M.ShockCooling(redshift=0.), lc, priors))
         x0[k] = pb['truth'] * (1 + 0.05 * np.random.default_rng(k).standard_normal((32, 5)))
-    pop = PopulationSampler(problems, 32, seed=100)
-    assert pop.indices == [0, 1, 2, 3, 4]
-    pop.run_mcmc(x0, 10)
-    pop.run_mcmc(None, 5)
+    solos = []
     for k, (model, lc, pri) in enumerate(problems):
         solo = EnsembleSampler(32, 5, M.ShockCooling(redshift=0.).engine_for(lc, priors=pri), seed=100 + k)
         solo.run_mcmc(x0[k], 10)
         solo.run_mcmc(None, 5)
-        assert np.array_equal(pop[k].get_chain(), solo.get_chain())
-        assert pop[k].chain.shape == (32, 15, 5)
+        solos.append(solo)
+    for batched in (True, False):  # one launch per half-step for all transients / one stream per transient
+        pop = PopulationSampler(problems, 32, seed=100)
+        assert pop.indices == [0, 1, 2, 3, 4]
+        pop.run_mcmc(x0, 10, batched=batched)
+        pop.run_mcmc(None, 5, batched=batched)
+        for k in range(5):
+            assert np.array_equal(pop[k].get_chain(), solos[k].get_chain())
+            assert np.array_equal(pop[k].get_log_prob(), solos[k].get_log_prob())
+            assert np.array_equal(pop[k].acceptance_fraction, solos[k].acceptance_fraction)
+            assert pop[k].chain.shape == (32, 15, 5)
     assert [list(partition(7, 3, r)) for r in range(3)] == [[0, 1, 2], [3, 4, 5], [6]]
+
+
+@pytest.mark.parametrize('nwalkers', [10, 22, 130])
+def test_odd_ensemble_sizes_match_oracle(nwalkers):
+    """Walker counts that are not multiples of the wavefront or workgroup size (and the emcee minimum 2 ndim)."""
+    pb, lc, m, eng, _ = _setup(32)
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(nwalkers).standard_normal((nwalkers, 5)))
+    s = EnsembleSampler(nwalkers, 5, eng, seed=31337)
+    s.run_mcmc(x0, 6)
+    ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 31337)
+    assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
