@@ -480,9 +480,10 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
             // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
             double lpr = 0.;
             if (pb.has_priors) {
-                double mine = 0.;
+                double qv = 0.;
                 for (int d = 0; d < kMaxDim; ++d)
-                    if (lane == d && d < pb.n_dim) mine = prior_term(my_prior, q[d]);
+                    if (lane == d) qv = q[d];
+                const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
                 for (int d = 0; d < pb.n_dim; ++d) lpr += __shfl(mine, d, 64);
             }
             if (lane == 0) {
