@@ -398,6 +398,9 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
 //   on the outcome issued up front (both candidate rows included);  lanes 0..n_par-1: ln of the proposal's parameters.
 // Every lane ends with the same proposal (bitwise); lane 0 of the chunk-0 workgroup publishes it.  Then all 256
 // threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
+// ND > 0: the walker dimension is a compile-time constant (loops over parameters unroll with exact trip counts and
+// the per-parameter arrays live in registers); ND == 0: any dimension up to kMaxDim.
+template <int ND>
 __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int bid, int have_prev,
                                  long long prev_row, int have_next, const DrawRec* __restrict__ draws,
                                  const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi, int n_echunks,
@@ -414,7 +417,9 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     PriorDev my_prior{0, 0, 0., 0., 0., 1.};
     if (lane < pb.n_dim && pb.has_priors && have_next) my_prior = pb.priors[lane];
     if (lane < 64) {
-        const int pp = (int)((g - 1) & 1), cp = (int)(g & 1), nd = sm.n_dim;
+        const int pp = (int)((g - 1) & 1), cp = (int)(g & 1);
+        constexpr int kD = ND > 0 ? ND : kMaxDim;     // array extent
+        const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
         DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
         if (have_next) dr = draws[i];
         // --- roles: which accept test (if any) this lane evaluates ---
@@ -426,18 +431,23 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
             rw = lane == 1 ? dr.wid : dr.pid;
             rslot = have_prev ? (lane == 1 ? dr.wprev : dr.pprev) : -1;
         }
-        double row[kMaxDim], qrow[kMaxDim], lp_cur = 0., nlp = 0.;
+        double row[kD], qrow[kD], lp_cur = 0., nlp = 0.;
         bool ok = false;
-        for (int d = 0; d < kMaxDim; ++d) row[d] = qrow[d] = 0.;
+#pragma unroll
+        for (int d = 0; d < kD; ++d) row[d] = qrow[d] = 0.;
         if (rw >= 0) {
             // everything the accept test and both outcomes need, in one wave of loads
             const double* xs = sm.X + (size_t)rw * nd;
-            for (int d = 0; d < nd; ++d) row[d] = xs[d];
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) row[d] = xs[d];
             lp_cur = sm.LP[rw];
             if (rslot >= 0) {
                 const SlotRec rc = sm.rec[pp][rslot];
                 const double* qs = sm.Q[pp] + (size_t)rslot * nd;
-                for (int d = 0; d < nd; ++d) qrow[d] = qs[d];
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) qrow[d] = qs[d];
                 if (sm.inline_finalize) {
                     double sum = pb.use_sigma ? 0. : pb.log_norm_const;
                     for (int k = 0; k < pb.n_parts; ++k) sum += sm.part[(size_t)rslot * pb.n_parts + k];
@@ -447,50 +457,65 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
                 }
                 ok = (rc.zl + nlp - rc.lp_old) > rc.lnu;  // emcee: (ndim-1) ln z + lp_new - lp_old > ln u
                 lp_cur = ok ? nlp : rc.lp_old;
-                if (ok)
-                    for (int d = 0; d < nd; ++d) row[d] = qrow[d];
+                if (ok) {
+#pragma unroll
+                    for (int d = 0; d < kD; ++d) row[d] = qrow[d];
+                }
             }
         }
         if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
             if (nlp != nlp) atomicExch(sm.err, 1);
             if (ok) {
-                for (int d = 0; d < nd; ++d) sm.X[(size_t)rw * nd + d] = row[d];
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) sm.X[(size_t)rw * nd + d] = row[d];
                 sm.LP[rw] = nlp;
                 atomicAdd((unsigned long long*)&sm.nacc[rw], 1ull);
             }
             if (sm.store_chain) {
                 double* crow = sm.chain + ((size_t)prev_row * sm.n_walkers + rw) * nd;
-                for (int d = 0; d < nd; ++d) crow[d] = row[d];
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) crow[d] = row[d];
                 sm.chain_lp[(size_t)prev_row * sm.n_walkers + rw] = lp_cur;
             }
         }
         if (have_next) {
             double q[kMaxDim], lq[kMaxDim];
             double arg = 1.;
-            for (int d = 0; d < kMaxDim; ++d) {
+#pragma unroll
+            for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
+#pragma unroll
+            for (int d = 0; d < kD; ++d) {
                 const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
                 q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
                 if (lane == d && d < pb.n_par) arg = q[d];
             }
             const double lp_i = __shfl(lp_cur, 1, 64);
             const double lg = log(arg);  // one logarithm per lane, all at once
-            for (int d = 0; d < kMaxDim; ++d) lq[d] = __shfl(lg, d, 64);
+#pragma unroll
+            for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
             double c[kNCoef];
             walker_coefficients(pb, q, lq, c);
             // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
             double lpr = 0.;
             if (pb.has_priors) {
                 double qv = 0.;
-                for (int d = 0; d < kMaxDim; ++d)
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
                     if (lane == d) qv = q[d];
                 const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
-                for (int d = 0; d < pb.n_dim; ++d) lpr += __shfl(mine, d, 64);
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) lpr += __shfl(mine, d, 64);
             }
             if (lane == 0) {
                 for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
                 sc[kNCoef] = lpr;
                 if (ec == 0) {  // publish the per-slot records
-                    for (int d = 0; d < nd; ++d) sm.Q[cp][(size_t)i * nd + d] = q[d];
+#pragma unroll
+                    for (int d = 0; d < kD; ++d)
+                        if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
                     sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
                     lprior[i] = lpr;
@@ -507,13 +532,14 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
 }
 
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
                                                  long long prev_row, int have_next,
                                                  const DrawRec* __restrict__ draws,
                                                  const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
                                                  int n_echunks, int do_thermal, double* __restrict__ coef,
                                                  double* __restrict__ lprior, double2* __restrict__ therm) {
-    step_body(pb, sm, blockIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, lo, hi, n_echunks, do_thermal,
+    step_body<ND>(pb, sm, blockIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, lo, hi, n_echunks, do_thermal,
               coef, lprior, therm);
 }
 
@@ -528,6 +554,7 @@ struct MultiItem {
     double* part;
 };
 
+template <int ND>
 __global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restrict__ items, int have_prev,
                                                        long long prev_row, int have_next, long long rel,
                                                        long long g, int thermal) {
@@ -535,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restri
     const int nh = it.sm.n_half;
     const int nec = thermal ? (it.pb.n_epochs + kBlock - 1) / kBlock : 1;
     if ((int)blockIdx.x >= nh * nec) return;
-    step_body(it.pb, it.sm, blockIdx.x, have_prev, prev_row, have_next,
+    step_body<ND>(it.pb, it.sm, blockIdx.x, have_prev, prev_row, have_next,
               have_next ? it.draws + (size_t)rel * nh : nullptr, have_prev ? it.draws + (size_t)(rel - 1) * nh : nullptr,
               g, 0, nh, nec, thermal, it.coef, it.lprior, it.therm);
 }
@@ -1098,9 +1125,21 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const bool thermal = have_next && fuse_thermal && e->dp.use_therm;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
-    hipLaunchKernelGGL(k_step, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, e->dp, ds,
-                       have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, nec, thermal ? 1 : 0, s->coef,
-                       s->lprior, s->therm);
+#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, \
+                                        e->dp, ds, have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, \
+                                        nec, thermal ? 1 : 0, s->coef, s->lprior, s->therm)
+    switch (ds.n_dim) {  // the fit dimensions of the supported models (+ sigma) get dedicated instantiations
+        case 2: LCF_STEP(2); break;
+        case 3: LCF_STEP(3); break;
+        case 4: LCF_STEP(4); break;
+        case 5: LCF_STEP(5); break;
+        case 6: LCF_STEP(6); break;
+        case 7: LCF_STEP(7); break;
+        case 8: LCF_STEP(8); break;
+        case 9: LCF_STEP(9); break;
+        default: LCF_STEP(0); break;
+    }
+#undef LCF_STEP
     LCF_HIP(hipGetLastError());
     s->pending = have_next;
     if (have_next) s->g_next = g + 1;
@@ -1495,6 +1534,9 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     size_t lds = 0;
     int max_nec = 1, max_parts = 1;
     const bool thermal = s0->e->dp.use_therm != 0;
+    int same_dim = s0->ds.n_dim;  // compile-time walker dimension when every transient has the same
+    for (int t = 0; t < n; ++t)
+        if (ss[t]->ds.n_dim != same_dim) same_dim = 0;
     for (int t = 0; t < n; ++t) {
         lcf_sampler* s = ss[t];
         s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
@@ -1518,9 +1560,18 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int64_t k = 0; k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
-        hipLaunchKernelGGL(k_step_multi, have_next ? gs : dim3((unsigned)nh, (unsigned)n), have_next ? bs : dim3(64), 0,
-                           st, ditems, have_prev ? 1 : 0, (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k,
-                           (long long)(g + k), (have_next && thermal) ? 1 : 0);
+#define LCF_STEPM(ND) hipLaunchKernelGGL(k_step_multi<ND>, have_next ? gs : dim3((unsigned)nh, (unsigned)n),              \
+                                         have_next ? bs : dim3(64), 0, st, ditems, have_prev ? 1 : 0,                  \
+                                         (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k, (long long)(g + k), \
+                                         (have_next && thermal) ? 1 : 0)
+        switch (same_dim) {
+            case 4: LCF_STEPM(4); break;
+            case 5: LCF_STEPM(5); break;
+            case 6: LCF_STEPM(6); break;
+            case 8: LCF_STEPM(8); break;
+            default: LCF_STEPM(0); break;
+        }
+#undef LCF_STEPM
         if (!have_next) break;
         const int parity = (int)((g + k) & 1);
 #define LCF_PM(V, L, T) hipLaunchKernelGGL((k_points_multi<V, L, T>), gp, bp, lds, st, ditems, parity)
