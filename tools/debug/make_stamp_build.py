@@ -9,7 +9,8 @@ def rep(a, b):
     global s
     assert a in s, a[:60]
     s = s.replace(a, b, 1)
-rep("__device__ inline void step_body(", "__device__ unsigned long long g_stamps[64 * 12];\n#define STAMP(k) do { if (stamp_on) { unsigned long long t_; asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_) :: \"memory\"); if (threadIdx.x == 0) g_stamps[i * 12 + (k)] = t_; } } while (0)\n__device__ inline void step_body(")
+rep("// ND > 0: the walker dimension is a compile-time constant", "__device__ unsigned long long g_stamps_decl_marker;\n// ND > 0: the walker dimension is a compile-time constant")
+rep("template <int ND>\n__device__ inline void step_body(", "__device__ unsigned long long g_stamps[64 * 12];\n#define STAMP(k) do { if (stamp_on) { unsigned long long t_; asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_) :: \"memory\"); if (threadIdx.x == 0) g_stamps[i * 12 + (k)] = t_; } } while (0)\ntemplate <int ND>\n__device__ inline void step_body(")
 rep("    const int i = bid / n_echunks, ec = bid % n_echunks;\n    const bool in_shard = do_thermal && i >= lo && i < hi;", "    const int i = bid / n_echunks, ec = bid % n_echunks;\n    const bool stamp_on = ec == 0 && i < 64 && have_prev && have_next;\n    STAMP(0);\n    const bool in_shard = do_thermal && i >= lo && i < hi;")
 rep("        if (have_next) dr = draws[i];\n", "        if (have_next) dr = draws[i];\n        STAMP(1);\n")
 rep("        if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i", "        STAMP(2);\n        if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i")
@@ -18,7 +19,7 @@ rep("            const double lg = log(arg);  // one logarithm per lane, all at 
 rep("            double c[kNCoef];\n            walker_coefficients(pb, q, lq, c);", "            STAMP(5);\n            double c[kNCoef];\n            walker_coefficients(pb, q, lq, c);\n            STAMP(6);")
 rep("            if (lane == 0) {\n                for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];", "            STAMP(7);\n            if (lane == 0) {\n                for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];")
 rep("    if (!have_next || !in_shard) return;\n    __syncthreads();", "    STAMP(8);\n    if (!have_next || !in_shard) return;\n    __syncthreads();\n    STAMP(9);")
-rep("    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);\n}\n\n__global__ __launch_bounds__(kBlock) void k_step(", "    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);\n    STAMP(10);\n}\n\n__global__ __launch_bounds__(kBlock) void k_step(")
+rep("    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);\n}\n\ntemplate <int ND>\n__global__ __launch_bounds__(kBlock) void k_step(", "    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);\n    STAMP(10);\n}\n\ntemplate <int ND>\n__global__ __launch_bounds__(kBlock) void k_step(")
 s += '\nextern "C" int lcf_debug_read_stamps(unsigned long long* out) {\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 12);\n}\n'
 os.makedirs(os.path.join(ROOT, 'build_variants'), exist_ok=True)
 tmp = os.path.join(ROOT, 'lightcurve_fitting_amd/csrc/_stamps_tmp.hip')
