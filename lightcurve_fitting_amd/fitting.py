@@ -15,6 +15,22 @@ PRIOR_WARNING = 'The p_max/p_min keywords are deprecated. Use the priors keyword
 MODEL_KWARGS_WARNING = 'The model_kwargs keyword is deprecated. These are now included in the model intialization.'
 
 
+def make_log_posterior(lc, model, priors=None, use_sigma=False, sigma_type='relative'):
+    """The ``log_posterior`` callable that the reference builds inside ``lightcurve_mcmc`` (fitting.py:121-128), backed
+    by the device engine.  ``f(p)`` with ``p`` of shape ``(ndim,)`` returns a float, exactly like the reference's
+    closure; with a C-contiguous ``(n, ndim)`` block it returns ``(n,)`` -- the form
+    ``emcee.EnsembleSampler(nwalkers, ndim, f, vectorize=True)`` calls once per half-step."""
+    engine = model.engine_for(lc, use_sigma=use_sigma, sigma_type=sigma_type, priors=priors)
+
+    def log_posterior(p):
+        p = np.asarray(p, dtype=np.float64)
+        out = engine.log_posterior(p)
+        return float(out[0]) if p.ndim == 1 else out
+
+    log_posterior.engine = engine
+    return log_posterior
+
+
 def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p_up=None,
                     nwalkers=100, nsteps=1000, nsteps_burnin=1000, model_kwargs=None,
                     show=False, save_plot_as='', save_sampler_as='', use_sigma=False, sigma_type='relative',
