@@ -214,6 +214,29 @@ def run_population(args):
         dist.destroy_process_group()
 
 
+def cpu_baseline_c(lc, budget_s=8.):
+    """The same evaluation through the plain-C oracle (oracle/lcf_oracle_c.c, gcc -O2, OpenMP over walkers): what an
+    optimised CPU port reaches, on the host cores a 1-GPU slot owns.  Reported next to the reference-shaped figure."""
+    import subprocess
+    from oracle import lcf_oracle as O
+    so = os.path.join(ROOT, 'oracle', 'liblcf_oracle.so')
+    if not os.path.exists(so):
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True, capture_output=True)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    bands = [O.band(n) for n in lc['filter']]
+    orc = O.ShockCoolingOracle(0., 1.5)
+    P = initial_walkers(64 * threads)
+    O.c_shock_cooling_loglike(orc, lc['MJD'], bands, lc['lum'], lc['dlum'], P[:threads], threads)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        O.c_shock_cooling_loglike(orc, lc['MJD'], bands, lc['lum'], lc['dlum'], P, threads)
+        n += len(P)
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'walker-steps/s', 'cores': threads, 'kind': 'port-c',
+            'sample': f'{n} log-likelihood evaluations of the same light curve in plain C (exact per-sample sums), '
+                      f'{dt:.1f} s on {threads} threads'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population'],
@@ -310,6 +333,10 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(lc)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+            try:
+                out['cpu_baseline_c'] = cpu_baseline_c(lc)
+            except Exception as exc:  # noqa: BLE001 - the extra reference point must never break the bench line
+                out['cpu_baseline_c'] = {'error': repr(exc)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

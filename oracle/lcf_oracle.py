@@ -466,3 +466,28 @@ def stretch_move_run(log_prob_fn, coords, nsteps, seed, a=2., log_prob0=None, ra
         chain[it] = x
         lps[it] = lp
     return chain, lps, nacc
+
+
+# --- C restatement (oracle/lcf_oracle_c.c), for full-size checks and an optimised-CPU reference point -----------------
+def c_shock_cooling_loglike(orc, t, bands, y, dy, P, n_threads=1):
+    """ShockCooling log-likelihood of an (n, 5) walker block through the plain-C oracle (OpenMP over walkers)."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'liblcf_oracle.so'))
+    uniq = list(dict.fromkeys(b.name for b in bands))
+    idx = np.ascontiguousarray([uniq.index(b.name) for b in bands], dtype=np.int32)
+    tabs = [band(n) for n in uniq]
+    off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(b.freq) for b in tabs])]), dtype=np.int32)
+    freq = np.ascontiguousarray(np.concatenate([b.freq for b in tabs]))
+    tnorm = np.ascontiguousarray(np.concatenate([b.tnorm for b in tabs]))
+    consts = np.array([orc.A, orc.a, orc.alpha, orc.eps1, orc.eps2, orc.L0, orc.T0, orc.ratio])
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    t, y, dy = (np.ascontiguousarray(x, dtype=np.float64) for x in (t, y, dy))
+    out = np.empty(len(P))
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.lcf_oracle_shock_cooling_loglike(
+        C.c_int(len(P)), P.ctypes.data_as(dp), C.c_int(len(t)), t.ctypes.data_as(dp), idx.ctypes.data_as(ip),
+        y.ctypes.data_as(dp), dy.ctypes.data_as(dp), off.ctypes.data_as(ip), freq.ctypes.data_as(dp),
+        tnorm.ctypes.data_as(dp), consts.ctypes.data_as(dp), C.c_double(orc.z), out.ctypes.data_as(dp),
+        C.c_int(int(n_threads)))
+    return out

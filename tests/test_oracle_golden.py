@@ -244,3 +244,25 @@ def test_sed_likelihoods():
         assert relerr(O.log_likelihood(*args, c[:, :2].T), g['sed/ll'][e]) < TOL
         assert relerr(O.log_likelihood(*args, c.T, True, 'relative'), g['sed/ll_rel'][e]) < TOL
         assert relerr(O.log_likelihood(*args, c.T, True, 'absolute'), g['sed/ll_abs'][e]) < TOL
+
+
+def test_c_oracle_matches_reference_numbers():
+    """oracle/lcf_oracle_c.c (plain C, no fast-math) against the reference's log-likelihoods, edge cases included."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    if not os.path.exists(os.path.join(ROOT, 'oracle', 'liblcf_oracle.so')):
+        subprocess.run(['make', '-C', os.path.join(ROOT, 'oracle')], check=True, capture_output=True)
+    g = golden('config2')
+    bands = [O.band(str(n)) for n in g['cfg2/names']]
+    got = O.c_shock_cooling_loglike(O.ShockCoolingOracle(0., 1.5), g['cfg2/t'], bands, g['cfg2/y'], g['cfg2/dy'],
+                                    g['cfg2/P'], n_threads=2)
+    assert relerr(got, g['cfg2/ll']) < TOL
+    s = golden('shockcooling')
+    bands = [O.band(str(n)) for n in s['scb/names']]
+    for tag, kw in VARIANTS.items():
+        got = O.c_shock_cooling_loglike(O.ShockCoolingOracle(0.01, **kw), s['scb/t'], bands, s['scb/y'], s['scb/dy'],
+                                        s['scb/P'])
+        assert relerr(got, s[f'scb/{tag}/ll']) < TOL
+    got = O.c_shock_cooling_loglike(O.ShockCoolingOracle(0.01), s['scb/t'], bands, s['scb/y'], s['scb/dy'], s['sce/P'])
+    assert relerr(got, s['sce/sc/ll']) < TOL  # zeros and NaNs where the reference has them
