@@ -151,6 +151,68 @@ def run_sed(args):
         'f32_vs_f64_lnL_relative_error': {'max': float(err.max()), 'median': float(np.median(err))}}), flush=True)
 
 
+def run_companion(args):
+    """BASELINE configs[2]: CompanionShocking (Kasen shock + SiFTO template), 8 filters x 1000 epochs = 8000 points,
+    512 walkers per GPU in one ensemble (4096 on 8 GPUs), walker-sharded with one all-gather per half-step.
+    Extra workload: prints its own JSON line."""
+    import torch
+    from lightcurve_fitting_amd import models as M
+    from lightcurve_fitting_amd.sampler import EnsembleSampler
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    rng = np.random.default_rng(SEED + 1)
+    bands = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'unfilt.']
+    epochs = np.sort(rng.uniform(57001., 57060., 1000))
+    t, names = np.repeat(epochs, 8), list(np.tile(bands, 1000))
+    q = np.array([57001., 0.5, 1.2, 57018., 1.05, 0.95, 0.9, 0.6])
+    peak = {'U': 2.1e20, 'B': 2.6e20, 'V': 2.4e20, 'g': 2.5e20, 'r': 2.2e20, 'i': 1.7e20, 'DLT40': 2.2e20,
+            'unfilt.': 2.2e20}
+    lum0 = np.array([peak[n] for n in names]) * np.exp(-0.5 * ((t - 57018.) / 12.) ** 2)
+    model = M.CompanionShocking({'MJD': t, 'filter': names, 'lum': lum0, 'dlum': 0.05 * lum0}, redshift=0.003)
+    model.device = local_rank
+    ytrue = model(t, names, *q)
+    lc = {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * rng.standard_normal(len(t))),
+          'dlum': 0.05 * np.maximum(ytrue, 1e17)}
+    priors = [M.UniformPrior(56990., 57010.), M.UniformPrior(0., 10.), M.UniformPrior(0., 10.),
+              M.UniformPrior(57005., 57030.), M.UniformPrior(0.5, 2.)] + [M.UniformPrior(0., 3.)] * 3
+    nw = 512 * world
+    sampler = EnsembleSampler(nw, 8, model.engine_for(lc, priors=priors), seed=SEED)
+    x0 = q * (1 + 0.01 * np.random.default_rng(SEED + 2).standard_normal((nw, 8)))
+    x0[:, [0, 3]] = q[[0, 3]] + 0.3 * np.random.default_rng(SEED + 3).standard_normal((nw, 2))
+    sampler.run_mcmc(x0, args.warmup, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    sampler.run_mcmc(None, args.steps, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'walker-steps/sec (emcee ensemble)', 'value': nw * args.steps / elapsed,
+                          'unit': 'walker-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                          'acceptance_fraction': float(sampler.acceptance_fraction.mean()),
+                          'config': {'workload': 'BASELINE configs[2]: CompanionShocking + SiFTO template, 512 walkers '
+                                                 'per GPU, 8 filters x 1000 epochs = 8000 points, float64',
+                                     'walkers': nw, 'points': 8000}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def run_population(args):
     """BASELINE configs[4]: population mode -- independent synthetic transients (config-2-like, 100 epochs x 6 filters
     = 600 points, own truth drawn +-20 %), 512 walkers each, transients partitioned over the GPUs (no communication).
@@ -239,7 +301,7 @@ def cpu_baseline_c(lc, budget_s=8.):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population'],
+    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population', 'companion'],
                     help="'mcmc' (default) = the headline configs[1] line; 'sed' = configs[3] extra line")
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -256,6 +318,8 @@ def main():
         return run_sed(args)
     if args.workload == 'population':
         return run_population(args)
+    if args.workload == 'companion':
+        return run_companion(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -244,6 +244,7 @@ class EnsembleSampler:
         self._chain = np.empty((0, nwalkers, ndim))
         self._lp = np.empty((0, nwalkers))
         self._naccepted = np.zeros(nwalkers, dtype=np.int64)
+        self._nsteps_counted = 0
         self._state = None
 
     def _native_comm(self):
@@ -289,6 +290,7 @@ class EnsembleSampler:
         self._chain = np.empty((0, self.nwalkers, self.ndim))
         self._lp = np.empty((0, self.nwalkers))
         self._naccepted[:] = 0
+        self._nsteps_counted = 0
 
     def _prepare(self, initial_state, skip_initial_state_check=False):
         """Validate and upload the starting positions (or continue from the stored state)."""
@@ -349,6 +351,7 @@ class EnsembleSampler:
             self._chain = np.concatenate([self._chain, chain])
             self._lp = np.concatenate([self._lp, lp])
         self._naccepted += self._native.naccepted() - self._acc0
+        self._nsteps_counted += nsteps
         x, lp = self._native.get_state()
         self._state = State(x, lp, None)
         return self._state
@@ -392,7 +395,8 @@ class EnsembleSampler:
 
     @property
     def acceptance_fraction(self):
-        return self._naccepted / max(1, self.iteration)
+        """Accepted proposals per walker and step since the last reset (steps run with ``store=False`` count)."""
+        return self._naccepted / max(1, self._nsteps_counted)
 
     @property
     def last_run_ms(self):
