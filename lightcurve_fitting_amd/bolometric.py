@@ -92,3 +92,64 @@ def spectrum_log_likelihood(filters, y, dy, T, R, z=0., sigma=None, sigma_type='
         cols.append(np.broadcast_to(np.asarray(sigma, dtype=float), T.shape))
     like = SpectrumLikelihood([(filters, y, dy)], z=z)
     return like(np.stack(cols, axis=-1)[None], sigma_type, precision)[0]
+
+
+def blackbody_grid_fit(epochs, z=0., T_grid=None, R_grid=None, precision='f64', device=0):
+    """Per-epoch blackbody fit on a dense (T, R) grid: the device evaluates every epoch's log-likelihood surface in
+    one launch; the posterior moments under the reference's default priors -- uniform in T, log-uniform in R
+    (``bolometric.py:729``) -- give the estimates the reference gets from ``curve_fit`` / a short MCMC per epoch.
+
+    Returns a dict of arrays over epochs: ``temp, radius`` (maximum likelihood), ``temp_mean, dtemp, radius_mean,
+    dradius, covTR`` (posterior moments), ``lum, dlum`` (Stefan-Boltzmann at the posterior mean) and ``lnL_max``."""
+    T_grid = np.linspace(1., 100., 128) if T_grid is None else np.asarray(T_grid, dtype=float)
+    R_grid = np.geomspace(0.01, 1000., 128) if R_grid is None else np.asarray(R_grid, dtype=float)
+    like = SpectrumLikelihood(epochs, z=z, device=device)
+    TT, RR = np.meshgrid(T_grid, R_grid, indexing='ij')
+    cand = np.broadcast_to(np.stack([TT.ravel(), RR.ravel()], axis=-1), (like.n_epochs, TT.size, 2))
+    lnl = like(np.ascontiguousarray(cand), precision=precision)                 # (n_epochs, nT * nR)
+    best = np.argmax(lnl, axis=1)
+    # quadrature weights: uniform prior in T -> dT; log-uniform prior in R -> d(ln R) on the geometric grid
+    wT = np.gradient(T_grid)
+    wR = np.gradient(np.log(R_grid))
+    w = np.exp(lnl - lnl.max(axis=1, keepdims=True)) * np.outer(wT, wR).ravel()
+    w /= w.sum(axis=1, keepdims=True)
+    Tm, Rm = w @ TT.ravel(), w @ RR.ravel()
+    dT = np.sqrt(np.maximum(w @ TT.ravel() ** 2 - Tm ** 2, 0.))
+    dR = np.sqrt(np.maximum(w @ RR.ravel() ** 2 - Rm ** 2, 0.))
+    cov = w @ (TT.ravel() * RR.ravel()) - Tm * Rm
+    lum, dlum = stefan_boltzmann(Tm, Rm, dT, dR, cov)
+    return dict(temp=TT.ravel()[best], radius=RR.ravel()[best], temp_mean=Tm, dtemp=dT, radius_mean=Rm, dradius=dR,
+                covTR=cov, lum=lum, dlum=dlum, lnL_max=lnl[np.arange(len(best)), best])
+
+
+def spectrum_mcmc_population(epochs, priors=None, z=0., nwalkers=10, burnin_steps=200, steps=100, T_range=(1., 100.),
+                             R_range=(0.01, 1000.), seed=0, use_sigma=False, sigma_type='relative'):
+    """``spectrum_mcmc`` (bolometric.py:87-190) for MANY epochs at once: one (T, R[, sigma]) ensemble per epoch, all
+    running in lock step on the device (population mode).  Defaults follow the reference (10 walkers, 200 burn-in +
+    100 steps, uniform prior on T, log-uniform on R).  Returns ``chains[n_epochs][steps * nwalkers, ndim]``."""
+    from .models import Blackbody, LogUniformPrior, UniformPrior
+    from .sampler import PopulationSampler
+    ndim = 3 if use_sigma else 2
+    if priors is None:
+        priors = [UniformPrior(*T_range), LogUniformPrior(*R_range)] + ([UniformPrior(0., 10.)] if use_sigma else [])
+    if nwalkers < 2 * ndim or nwalkers % 2:
+        raise ValueError('nwalkers must be even and at least 2 * ndim')
+    problems, x0 = [], {}
+    rng = np.random.default_rng(seed)
+    for k, (filts, y, dy) in enumerate(epochs):
+        lc = {'MJD': np.zeros(len(y)), 'filter': list(filts), 'lum': np.asarray(y, float), 'dlum': np.asarray(dy, float)}
+        model = Blackbody(redshift=z)
+        if use_sigma:
+            model.input_names.append('\\sigma')
+        problems.append((model, lc, priors, dict(use_sigma=use_sigma, sigma_type=sigma_type)))
+        # starting guesses: uniform over the prior ranges like the reference (bolometric.py:166)
+        cols = [rng.uniform(*T_range, nwalkers), np.exp(rng.uniform(*np.log(R_range), nwalkers))]
+        if use_sigma:
+            cols.append(rng.uniform(0., 1., nwalkers))
+        x0[k] = np.column_stack(cols)
+    pop = PopulationSampler(problems, nwalkers, seed=seed)
+    pop.run_mcmc(x0, burnin_steps, store=False)
+    for s in pop.samplers.values():
+        s.reset()
+    pop.run_mcmc(None, steps)
+    return [pop[k].flatchain for k in range(len(epochs))]

@@ -168,10 +168,10 @@ class PopulationSampler:
         self.indices = list(partition(len(problems), world, rank))
         self.samplers = {}
         for k in self.indices:
-            model, lc, priors = problems[k]
+            model, lc, priors, *extra = problems[k]  # optional 4th entry: engine keywords (use_sigma, sigma_type)
             if device is not None:
                 model.device = device
-            eng = model.engine_for(lc, priors=priors)
+            eng = model.engine_for(lc, priors=priors, **(extra[0] if extra else {}))
             self.samplers[k] = EnsembleSampler(nwalkers, eng.ndim, eng, seed=seed + k, a=a)
         self.nwalkers = nwalkers
 

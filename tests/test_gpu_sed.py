@@ -86,3 +86,27 @@ def test_pseudo_and_stefan_boltzmann():
                   [O.pseudo(10., 1., 0.01), O.pseudo(20., 2., 0.01)]) < 1e-13
     lum, dlum = B.stefan_boltzmann(10., 1., 0.5, 0.1, 0.01)
     assert dlum > 0 and lum == B.stefan_boltzmann(10., 1.)
+
+
+def test_grid_fit_and_population_mcmc_recover_the_blackbody():
+    """The two per-epoch fitters built on the engine: a dense (T, R) grid posterior (curve_fit's job in the reference,
+    bolometric.py:483-534) and spectrum_mcmc for many epochs at once (bolometric.py:87-190)."""
+    rng = np.random.default_rng(12)
+    names = ['U', 'B', 'V', 'g', 'r', 'i']
+    bands = [O.band(n) for n in names]
+    truth = [(8., 3.), (15., 1.5), (30., 0.8), (12., 6.)]
+    epochs = []
+    for Tt, Rt in truth:
+        ytrue = np.array([O.synthesize_blackbody(b, Tt, Rt, 0.01) for b in bands])
+        epochs.append((names, ytrue * (1 + 0.02 * rng.standard_normal(6)), 0.02 * ytrue))
+    fit = B.blackbody_grid_fit(epochs, z=0.01, T_grid=np.linspace(2., 60., 256), R_grid=np.geomspace(0.1, 30., 256))
+    for k, (Tt, Rt) in enumerate(truth):
+        assert abs(fit['temp_mean'][k] - Tt) < max(4 * fit['dtemp'][k], 0.3)
+        assert abs(fit['radius_mean'][k] - Rt) < max(4 * fit['dradius'][k], 0.05 * Rt)
+        assert fit['covTR'][k] < 0.  # hotter <-> smaller at fixed flux
+        assert fit['lum'][k] == pytest.approx(B.stefan_boltzmann(Tt, Rt), rel=0.2)
+    chains = B.spectrum_mcmc_population(epochs, z=0.01, nwalkers=16, burnin_steps=300, steps=100, T_range=(2., 60.),
+                                        R_range=(0.1, 30.), seed=3)
+    for k, (Tt, Rt) in enumerate(truth):
+        assert chains[k].shape == (1600, 2)
+        assert abs(np.median(chains[k][:, 0]) - Tt) < 0.15 * Tt and abs(np.median(chains[k][:, 1]) - Rt) < 0.2 * Rt
