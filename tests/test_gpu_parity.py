@@ -313,3 +313,29 @@ def test_log_posterior_callable_and_degenerate_inputs():
     bad = lc_dict(lc['MJD'], lc['filter'], lc['lum'].copy(), lc['dlum'])
     bad['lum'][5] = np.nan
     assert np.all(np.isnan(M.ShockCooling(redshift=0.01).log_likelihood(bad, s['scb/P'][:4])))
+
+
+def test_device_pointer_entry_points_with_torch_tensors():
+    """lcf_log_likelihood_dev / lcf_log_posterior_dev: walker block and output stay in HBM (torch tensors), work is
+    enqueued on torch's current stream without a host round-trip; results equal the host-pointer entry points."""
+    import torch
+    s, lc = shockcooling_case()
+    m = M.ShockCooling(redshift=0.01)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    eng = m.engine_for(lc, priors=priors)
+    P = np.tile(s['scb/P'], (20, 1))
+    want_ll, want_lp = eng.log_likelihood(P), eng.log_posterior(P)
+    dP = torch.tensor(P, dtype=torch.float64, device='cuda')
+    out = torch.empty(len(P), dtype=torch.float64, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.log_likelihood_dev(len(P), dP.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want_ll)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.log_likelihood_dev(len(P), dP.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                               posterior=True)
+        doubled = out * 2.  # consumer on the same stream sees the result without any host synchronisation
+    side.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want_lp)
+    assert np.array_equal(doubled.cpu().numpy(), 2. * want_lp)
