@@ -408,7 +408,8 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
                                  double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
     const int i = bid / n_echunks, ec = bid % n_echunks;
-    const bool in_shard = do_thermal && i >= lo && i < hi;
+    const bool mine = i >= lo && i < hi;       // this rank evaluates the likelihood of slot i
+    const bool in_shard = do_thermal && mine;
     if (ec > 0 && !in_shard) return;
     const int lane = threadIdx.x;
     const int ep = ec * kBlock + lane;
@@ -492,6 +493,17 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
                 if (lane == d && d < pb.n_par) arg = q[d];
             }
             const double lp_i = __shfl(lp_cur, 1, 64);
+            if (!mine) {
+                // another rank evaluates this proposal: only what later accept tests need is published here
+                // (its log-prior reaches this rank inside the gathered log-posterior)
+                if (lane == 0 && ec == 0) {
+#pragma unroll
+                    for (int d = 0; d < kD; ++d)
+                        if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
+                    sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, 0.};
+                }
+                return;
+            }
             const double lg = log(arg);  // one logarithm per lane, all at once
 #pragma unroll
             for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
@@ -1122,7 +1134,10 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const long long rel = g - s->g_run0;
     const DrawRec* draws = have_next ? s->d_draws + (size_t)rel * ds.n_half : nullptr;
     const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
-    const bool thermal = have_next && fuse_thermal && e->dp.use_therm;
+    // with several ranks most slots are other ranks' (light wave-0 work only): one-wave workgroups keep all of them
+    // resident at once, and the shard's thermal states get their own launch (launch_eval)
+    const bool sharded = lo > 0 || hi < ds.n_half;
+    const bool thermal = have_next && fuse_thermal && e->dp.use_therm && !sharded;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
 #define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, \
@@ -1335,7 +1350,8 @@ lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void*
     const long long g = s->g_run0 + 2 * (step - s->run_first) + half;
     if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
     s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
-    return launch_next(s, true, false, 0, 0, stream ? (hipStream_t)stream : s->e->stream);
+    // the shard is not known yet: every slot gets its coefficients (lcf_sampler_half_step knows it and is cheaper)
+    return launch_next(s, true, false, 0, s->ds.n_half, stream ? (hipStream_t)stream : s->e->stream);
 }
 // propose + evaluate in one call: the shard is known, so the thermal states of [lo, hi) are computed by the same
 // launch that draws the proposals (3 launches per half-step and rank: k_step, k_points, k_finalize).
@@ -1348,7 +1364,8 @@ lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int
     hipStream_t st = stream ? (hipStream_t)stream : s->e->stream;
     s->ds.inline_finalize = 0;
     if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st);
+    const bool fused = s->e->dp.use_therm != 0 && lo == 0 && hi == s->ds.n_half;
+    return launch_eval(s, lo, hi, fused, true, st);
 }
 
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
@@ -1463,7 +1480,8 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     LCF_HIP(hipEventRecord(s->ev0, st));
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
         if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-        if (lcf_status r = launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st)) return r;
+        const bool fused = s->e->dp.use_therm != 0 && c->n_ranks == 1;
+        if (lcf_status r = launch_eval(s, lo, hi, fused, true, st)) return r;
         double* buf = s->ds.newlp[(s->g_next - 1) & 1];
         if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo, buf, (size_t)width, /*ncclDouble*/ 8, c->comm, st),
                                       "ncclAllGather"))
