@@ -135,7 +135,9 @@ lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant);
 lcf_status lcf_log_likelihood(lcf_engine* e, int64_t n, const double* P, double* out);
 /* log_posterior closure (fitting.py:121-128): -inf where a prior excludes the walker (likelihood skipped). */
 lcf_status lcf_log_posterior(lcf_engine* e, int64_t n, const double* P, double* out);
-/* Same with DEVICE pointers, enqueued on `stream` (a hipStream_t; NULL = the engine's own stream), no host sync. */
+/* Same with DEVICE pointers, enqueued on `stream` (a hipStream_t), no host sync.  NULL selects the engine's own
+ * non-blocking stream, which is NOT ordered with the legacy default stream: pass a real stream to chain with other
+ * work (the Python driver runs under a side stream for that reason). */
 lcf_status lcf_log_likelihood_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream);
 lcf_status lcf_log_posterior_dev(lcf_engine* e, int64_t n, const double* dP, double* dout, void* stream);
 

@@ -48,16 +48,28 @@ class NativeBackend:
         self.ns = native_sampler
         self.n_half = native_sampler.nwalkers // 2
         self._newlp = {}
-        self._stream = None
+        self._side = None
 
     def begin(self, first_step, nsteps, split, store):
         self.ns.begin(first_step, nsteps, split, store)
 
     def stream(self):
-        if self._stream is None:
-            import torch
-            self._stream = torch.cuda.current_stream().cuda_stream
-        return self._stream
+        """Raw handle of torch's current stream.  The native ABI reads handle 0 as "the engine's own stream", which
+        is NOT ordered with torch's default stream: callers run under :meth:`stream_context` (a real side stream)."""
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def stream_context(self):
+        """Context under which kernels enqueued through the ABI and torch collectives share one (non-default) stream."""
+        import torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.ns.engine.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def stream_sync(self):
+        if self._side is not None:
+            self._side.synchronize()
 
     def propose(self, step, half):
         self.ns.propose(step, half, self.stream())
@@ -116,6 +128,16 @@ class ShardedStretchDriver:
         """``split``: 'random' | 'identity' | int32 array (nsteps, nwalkers), see ``NativeSampler._split``."""
         b = self.backend
         b.begin(first_step, nsteps, split, store)
+        if hasattr(b, 'stream_context'):
+            with b.stream_context():
+                self._loop(first_step, nsteps)
+            b.stream_sync()
+        else:
+            self._loop(first_step, nsteps)
+        b.finish()
+
+    def _loop(self, first_step, nsteps):
+        b = self.backend
         for k in range(nsteps):
             step = first_step + k
             for half in (0, 1):
@@ -138,7 +160,6 @@ class ShardedStretchDriver:
                         if hi > lo and r != self.rank:
                             newlp[lo:hi].copy_(self._recv[r * self.width:r * self.width + (hi - lo)])
                 b.accept(step, half)
-        b.finish()
 
 
 def partition(n_items, world_size, rank):

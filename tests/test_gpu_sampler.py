@@ -206,3 +206,47 @@ def test_odd_ensemble_sizes_match_oracle(nwalkers):
     s.run_mcmc(x0, 6)
     ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 31337)
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
+
+
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_emulated_multi_rank_run_on_one_gpu(ranks):
+    """Every kernel path of a multi-GPU run except RCCL itself: `ranks` samplers play the ranks of one ensemble on
+    one device (same seed, each evaluating only its shard through lcf_sampler_half_step, with light proposals for
+    the other shards), the all-gather is emulated by device-to-device copies between their newlp buffers.  Every
+    emulated rank must end with the chain of the fused single-GPU run, bit for bit."""
+    import torch
+    from lightcurve_fitting_amd.engine import NativeSampler
+    from lightcurve_fitting_amd.sampler import NativeBackend, shard_bounds
+    pb, lc, m, eng, x0 = _setup(48)
+    nsteps, seed, nh = 7, 99, 24
+    ref = NativeSampler(eng, 48, seed)
+    ref.set_state(x0)
+    ref.run(0, nsteps, 'random', True)
+    samplers = [NativeSampler(eng, 48, seed) for _ in range(ranks)]
+    backs = [NativeBackend(s) for s in samplers]
+    for s in samplers:
+        s.set_state(x0)
+        s.begin(0, nsteps, 'random', True)
+    bounds = [shard_bounds(nh, ranks, r)[:2] for r in range(ranks)]
+    side = torch.cuda.Stream()  # a real stream: handle 0 would mean "the engine's own stream" to the ABI
+    with torch.cuda.stream(side):
+        st = side.cuda_stream
+        assert st != 0
+        for step in range(nsteps):
+            for half in (0, 1):
+                for r, s in enumerate(samplers):
+                    s.half_step(step, half, *bounds[r], st)
+                views = [b.newlp() for b in backs]      # current parity's buffers
+                for r, (lo, hi) in enumerate(bounds):   # "all-gather": rank r's shard reaches every other rank
+                    for q in range(ranks):
+                        if q != r and hi > lo:
+                            views[q][lo:hi].copy_(views[r][lo:hi])
+                for s in samplers:
+                    s.accept(step, half, st)
+    side.synchronize()
+    want_chain, want_lp = ref.get_chain()
+    for s in samplers:
+        s.check()
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
+        assert np.array_equal(s.naccepted(), ref.naccepted())
