@@ -203,6 +203,8 @@ lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGP
  * in the process).  One rank obtains an id, every rank creates its communicator with it (collective call). */
 typedef struct { char internal[128]; } lcf_comm_id;
 typedef struct lcf_comm lcf_comm;
+/* Local, non-collective check that RCCL can be bound (call it on every rank and agree before the collective calls). */
+lcf_status lcf_comm_probe(const char* rccl_path);
 lcf_status lcf_comm_unique_id(const char* rccl_path, lcf_comm_id* out);
 lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t n_ranks, int32_t rank, int32_t device,
                            lcf_comm** out);

@@ -1436,6 +1436,8 @@ struct lcf_comm {
     int n_ranks = 1, rank = 0;
 };
 
+lcf_status lcf_comm_probe(const char* rccl_path) { return rccl_load(rccl_path); }
+
 lcf_status lcf_comm_unique_id(const char* rccl_path, lcf_comm_id* out) {
     if (!out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     if (lcf_status st = rccl_load(rccl_path)) return st;

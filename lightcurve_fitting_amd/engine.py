@@ -97,6 +97,7 @@ SIGNATURES = [
     ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
+    ('lcf_comm_probe', C.c_int, [C.c_char_p]),
     ('lcf_comm_unique_id', C.c_int, [C.c_char_p, C.c_void_p]),
     ('lcf_comm_create', C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_comm_destroy', None, [C.c_void_p]),
@@ -405,6 +406,11 @@ def rccl_library_path():
 class NativeComm:
     """An RCCL communicator owned by the native library, bootstrapped over an initialised torch.distributed group
     (the 128-byte unique id is broadcast from rank 0)."""
+
+    @staticmethod
+    def probe():
+        """True if RCCL can be bound in this process (local check, no communication)."""
+        return load_library().lcf_comm_probe(rccl_library_path().encode()) == 0
 
     def __init__(self, device, group=None):
         import torch.distributed as dist

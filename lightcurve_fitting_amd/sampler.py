@@ -279,20 +279,25 @@ class EnsembleSampler:
             import torch.distributed as dist
             from .engine import NativeComm
             world = dist.get_world_size(self._group)
-            ok = self.native_collectives and (self.nwalkers // 2) % world == 0
+            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+
+            def agreed(ok):  # logical AND over the ranks
+                flag = torch.tensor([1 if ok else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+                return int(flag.item()) == 1
+
+            # 1. everything that can fail locally (options, shard shape, binding RCCL) BEFORE any collective RCCL call,
+            #    so that no rank is left waiting in ncclCommInitRank for one that bailed out
             comm = None
-            if ok:
+            if agreed(self.native_collectives and (self.nwalkers // 2) % world == 0 and NativeComm.probe()):
                 try:
                     comm = NativeComm(self.engine.device, self._group)
-                except Exception:  # noqa: BLE001 - any failure means: use the torch.distributed path
+                except Exception:  # noqa: BLE001 - then every rank falls back to the torch.distributed path
                     comm = None
-            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
-            flag = torch.tensor([1 if comm is not None else 0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
-            if int(flag.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                comm = None
+                if not agreed(comm is not None):
+                    if comm is not None:
+                        comm.close()
+                    comm = None
             self._comm = comm if comm is not None else False
         return self._comm or None
 
