@@ -115,6 +115,38 @@ def cpu_baseline(lc, budget_s=12., max_evals=128):
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
 
 
+def init_distributed():
+    """(torch.distributed or None, rank, world, local_rank) from the launcher's environment, one process per GPU over
+    RCCL.  Dry runs on a single-GPU box: LCF_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and uses gloo (RCCL refuses
+    two ranks on one device); the numbers of such a run are meaningless, the code path is the real one."""
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world == 1:
+        torch.cuda.set_device(0)
+        return None, 0, 1, 0
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    return dist, rank, world, local_rank
+
+
+def max_over_ranks(dist, elapsed):
+    if dist is None:
+        return elapsed
+    import torch
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item())
+
+
 def run_sed(args):
     """BASELINE configs[3]: per-epoch blackbody SED grid, 10 000 epochs x 6 filters (UBVgri) x 128 (T, R) candidates,
     float32 arithmetic with the float64 kernel as the error reference.  Extra workload: prints its own JSON line."""
@@ -158,15 +190,7 @@ def run_companion(args):
     import torch
     from lightcurve_fitting_amd import models as M
     from lightcurve_fitting_amd.sampler import EnsembleSampler
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dist, rank, world, local_rank = init_distributed()
     rng = np.random.default_rng(SEED + 1)
     bands = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'unfilt.']
     epochs = np.sort(rng.uniform(57001., 57060., 1000))
@@ -196,10 +220,7 @@ def run_companion(args):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(dist, elapsed)
     if rank == 0:
         print(json.dumps({'metric': 'walker-steps/sec (emcee ensemble)', 'value': nw * args.steps / elapsed,
                           'unit': 'walker-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -220,15 +241,7 @@ def run_population(args):
     import torch
     from lightcurve_fitting_amd import models as M
     from lightcurve_fitting_amd.sampler import PopulationSampler
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dist, rank, world, local_rank = init_distributed()
     n_tr, nw = 32 * world, 512
     rng = np.random.default_rng(SEED + 5)
     priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
@@ -259,10 +272,7 @@ def run_population(args):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(dist, elapsed)
     if rank == 0:
         print(json.dumps({'metric': 'walker-steps/sec (population of independent ensembles)',
                           'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
@@ -320,19 +330,8 @@ def main():
         return run_population(args)
     if args.workload == 'companion':
         return run_companion(args)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
+    dist, rank, world, local_rank = init_distributed()
     force_sharded = world == 1 and os.environ.get('LCF_BENCH_FORCE_SHARDED') == '1'
     if force_sharded:  # diagnostic: exercise the multi-GPU code path (RCCL all-gather included) with one rank
         import torch.distributed as dist
@@ -361,10 +360,7 @@ def main():
     sampler.run_mcmc(None, args.steps, store=False)        # EXACTLY K steps; returns after the device has finished
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(dist, elapsed)
     value = n_walkers * args.steps / elapsed
 
     out = None
