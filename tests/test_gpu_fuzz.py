@@ -1,0 +1,101 @@
+"""Seeded randomised parity sweep: random light curves (any filters of the registry, ragged or gridded epochs), random
+redshifts, every model family and band-sum variant, parameters inside AND outside their physical domain -- engine
+(through the C ABI) against the CPU oracle, NaN/zero patterns included."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from helpers import lc_dict
+from lightcurve_fitting_amd import filters as F, models as M
+from oracle import lcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ALL = [f.name for f in F.all_filters if f.filename]
+SIFTO_OK = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40']
+
+
+def _light_curve(rng, pool, n):
+    names = list(rng.choice(pool, n))
+    if rng.random() < 0.5:  # gridded epochs (thermal states shared per epoch)
+        t = rng.choice(np.sort(rng.uniform(0.3, 30., max(2, n // 4))), n)
+    else:
+        t = rng.uniform(0.3, 30., n)
+    y = 10 ** rng.uniform(19., 21., n)
+    dy = y * rng.uniform(0.01, 0.2, n)
+    return t, names, y, dy
+
+
+def _params(rng, lo, hi, n, p_bad):
+    P = rng.uniform(lo, hi, (n, len(lo)))
+    bad = rng.random(P.shape) < p_bad
+    P[bad] *= rng.choice([-1., 0.], size=bad.sum())  # out-of-domain: power() zeroing, NaNs
+    return P
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_shock_cooling_family_fuzz(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 400))
+    pool = list(rng.choice(ALL, int(rng.integers(1, 9)), replace=False))
+    t, names, y, dy = _light_curve(rng, pool, n)
+    z = float(rng.choice([0., 0.003, 0.05, 0.7]))
+    bands = [O.band(x) for x in names]
+    lc = lc_dict(t, names, y, dy)
+    kw = dict(n=float(rng.choice([1.5, 3.])), RW=bool(rng.integers(2)))
+    variant = int(rng.integers(3))
+    cases = [
+        (M.ShockCooling(redshift=z, **kw), ('ShockCooling', O.ShockCoolingOracle(z, **kw)),
+         _params(rng, [0.1, 0.05, 0.2, 0.1, -5.], [5., 3., 10., 8., 10.], 12, 0.08)),
+        (M.ShockCooling2(redshift=z, **kw), ('ShockCooling2', O.ShockCoolingOracle(z, **kw)),
+         _params(rng, [1., 0.1, 1., -5.], [80., 20., 60., 10.], 12, 0.08)),
+        (M.ShockCooling4(redshift=z), ('ShockCooling4', O.ShockCooling4Oracle(z)),
+         _params(rng, [0.1, 0.05, 0.2, 0.1, -5.], [5., 3., 10., 8., 10.], 12, 0.08)),
+    ]
+    for model, orc, P in cases:
+        eng = model.engine_for(lc)
+        eng.set_variant(variant)
+        want_y = O.evaluate(orc, t, bands, P.T).T
+        assert relerr(eng.evaluate(P), want_y) < 2e-11, (type(model).__name__, variant, z)
+        want = O.log_likelihood(orc, t, bands, y, dy, P.T)
+        got = model.log_likelihood(lc, P)
+        assert relerr(got, want) < 2e-11, (type(model).__name__, variant, z)
+        sig = np.column_stack([P, rng.uniform(0., 3., len(P))])
+        mode = str(rng.choice(['relative', 'absolute']))
+        model.engine_for(lc, True, mode).set_variant(variant)
+        want = O.log_likelihood(orc, t, bands, y, dy, sig.T, True, mode)
+        assert relerr(model.log_likelihood(lc, sig, True, mode), want) < 2e-11
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_companion_family_fuzz(seed):
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(8, 300))
+    pool = list(rng.choice(SIFTO_OK, int(rng.integers(2, 8)), replace=False))
+    if 'DLT40' in pool and rng.random() < 0.5:
+        pool.append('unfilt.')  # valid only together with DLT40 (models.py:704-706)
+    t, names, y, dy = _light_curve(rng, pool, n)
+    t = 57000. + 3. * t
+    z = float(rng.choice([0., 0.003, 0.05]))
+    bands = [O.band(x) for x in names]
+    lc = lc_dict(t, names, y, dy)
+    variant = int(rng.integers(3))
+    lo = [56990., 0.02, 0.1, 57010., 0.6, 0.5, 0.5, 0.2]
+    hi = [57010., 3., 4., 57040., 1.6, 1.5, 1.5, 2.]
+    for v, cls in ((1, M.CompanionShocking), (2, M.CompanionShocking2), (3, M.CompanionShocking3)):
+        P = rng.uniform(lo, hi, (10, 8))
+        if v > 1:
+            P = np.column_stack([P[:, :5], rng.uniform(-4., 4., (10, 2))])
+        if v == 3:
+            P[:, 2] = rng.uniform(0., 180., 10)
+        bad = rng.random(P.shape) < 0.05
+        bad[:, [0, 3]] = False
+        P[bad] *= -1.
+        model = cls(lc, redshift=z)
+        orc = ('CompanionShocking', O.CompanionShockingOracle(bands, y, z, v))
+        eng = model.engine_for(lc)
+        eng.set_variant(variant)
+        want_y = np.array([O.evaluate(orc, t, bands, p) for p in P])
+        assert relerr(eng.evaluate(P), want_y) < 2e-11, (v, variant, z)
+        want = np.array([O.log_likelihood(orc, t, bands, y, dy, p) for p in P])
+        assert relerr(model.log_likelihood(lc, P), want) < 2e-11, (v, variant, z)
