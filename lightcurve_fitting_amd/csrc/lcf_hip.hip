@@ -1,13 +1,17 @@
 // MI355X (gfx950) batched light-curve log-likelihood engine: kernels + C ABI (include/lcf.h).
 //
 // Data layout in HBM (all float64 unless noted):
-//   photometry  t[N], y[N], dy[N], int32 pt_off[N], pt_cnt[N], pt_filt[N], pt_orig[N]   -- sorted by filter
-//   band tables tab[sum K] as interleaved (a_k, W_k) pairs (16 B, one ds_read_b128 per sample)
-//   walkers     P[n][n_dim] row-major; derived coefficients coef[n][8]; partial chi^2 sums part[n][n_chunks]
-// Work decomposition: workgroup = (walker w, chunk c of 256 filter-sorted points); lane = one data point.  The
-// chunk's band-table slice is staged in LDS once per workgroup; lanes of a wave read the same LDS address
-// (broadcast) because neighbouring points share a filter.  Reductions are wave shuffles + a fixed-order LDS sum:
-// no float atomics anywhere, results are bitwise reproducible run to run and independent of the GPU count.
+//   photometry  t[N], y[N], dy[N], 1/dy[N], int32 pt_filt[N], pt_orig[N], pt_epoch[N], int4 pt_desc[N], 1/t_min[N]
+//               -- points stable-sorted by filter; distinct observation times epoch_t[n_epochs]
+//   band tables tab[] = per filter [full | Gauss-compressed] interleaved (a_k, W_k) pairs, each padded to quads
+//   walkers     P[n][n_dim] row-major; derived coefficients coef[n][8]; thermal states therm[n][n_epochs] (1/T, R^2);
+//               partial chi^2 sums part[n][n_parts]
+// Work decomposition (k_points): workgroup = (walker w, part j) walks the point chunks j, j + n_parts, ... of 256
+// filter-sorted points; lane = one data point.  The exp table and all band tables are staged in LDS once per
+// workgroup; lanes of a wave read the same LDS address (broadcast) because neighbouring points share a filter.
+// Reductions are wave shuffles + a fixed-order LDS sum: no float atomics anywhere, results are bitwise reproducible
+// run to run and independent of the GPU count.  The sampler (k_step, k_draws, k_make_perm), the multi-transient
+// launches (k_*_multi) and the RCCL-driven sharded run live further down; the SED engine is in lcf_sed.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
