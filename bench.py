@@ -109,10 +109,18 @@ def cpu_baseline(lc, budget_s=12., max_evals=128):
         O.log_likelihood(model, lc['MJD'], bands, lc['lum'], lc['dlum'], P[n], reference_shaped=True)
         n += 1
     dt = time.perf_counter() - t0
+    # second figure: the NumPy form vectorised over walkers -- the reference's own dense branch
+    # (models.py:1163-1164), one process
+    Pv = initial_walkers(64)
+    tv = time.perf_counter()
+    O.log_likelihood(model, lc['MJD'], bands, lc['lum'], lc['dlum'], Pv.T)
+    dtv = time.perf_counter() - tv
     return {'value': n / dt, 'unit': 'walker-steps/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n} per-walker log-likelihood evaluations of the same 3000-point light curve '
                       f'(oracle in reference-shaped mode: Python loop over points, {ALG_SAMPLES} Planck samples each), '
-                      f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+                      f'{dt:.1f} s on 1 of {os.cpu_count()} host cores',
+            'ideal_pool_value': n / dt * (os.cpu_count() or 1), 'host_cores': os.cpu_count(),
+            'vectorised_numpy_value': len(Pv) / dtv}
 
 
 def init_distributed():
