@@ -542,10 +542,13 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     if (!have_next || !in_shard) return;
     __syncthreads();
     if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
-    if (ep >= pb.n_epochs) return;
-    double T, pref;
-    thermal_state(pb, sc, t_ep, T, pref);
-    therm[(size_t)i * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
+    // a workgroup covers kBlock epochs with blockDim.x threads (64-thread workgroups when there are few epochs)
+    const int ep_end = min((ec + 1) * kBlock, pb.n_epochs);
+    for (int e2 = ep; e2 < ep_end; e2 += blockDim.x) {
+        double T, pref;
+        thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, pref);
+        therm[(size_t)i * pb.n_epochs + e2] = make_double2(T > 0. ? 1. / T : 0., pref);
+    }
 }
 
 template <int ND>
@@ -1144,7 +1147,7 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const bool thermal = have_next && fuse_thermal && e->dp.use_therm && !sharded;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
-#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)(ds.n_half * nec)), dim3(thermal ? kBlock : 64), 0, st, \
+#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)(ds.n_half * nec)), dim3(thermal && e->dp.n_epochs > kFewEpochs ? kBlock : 64), 0, st, \
                                         e->dp, ds, have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, \
                                         nec, thermal ? 1 : 0, s->coef, s->lprior, s->therm)
     switch (ds.n_dim) {  // the fit dimensions of the supported models (+ sigma) get dedicated instantiations
@@ -1556,7 +1559,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     }
     std::vector<MultiItem> items(n);
     size_t lds = 0;
-    int max_nec = 1, max_parts = 1;
+    int max_nec = 1, max_parts = 1, max_epochs = 0;
     const bool thermal = s0->e->dp.use_therm != 0;
     int same_dim = s0->ds.n_dim;  // compile-time walker dimension when every transient has the same
     for (int t = 0; t < n; ++t)
@@ -1567,6 +1570,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         s->ds.inline_finalize = 1;
         items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm, s->part};
         lds = std::max(lds, s->e->lds_bytes);
+        max_epochs = std::max(max_epochs, s->e->dp.n_epochs);
         max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
         max_parts = std::max(max_parts, s->e->dp.n_parts);
     }
@@ -1580,7 +1584,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     hipEvent_t ev0 = s0->ev0, ev1 = s0->ev1;
     if (err == hipSuccess) err = hipEventRecord(ev0, st);
     const dim3 gs((unsigned)(nh * max_nec), (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
-    const dim3 bs(thermal ? kBlock : 64), bp(kBlock);
+    const dim3 bs(thermal && max_epochs > kFewEpochs ? kBlock : 64), bp(kBlock);
     for (int64_t k = 0; k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
