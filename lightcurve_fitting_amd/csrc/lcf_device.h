@@ -11,6 +11,7 @@ namespace lcf {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kFewEpochs = 128;  // up to this many epochs one wave per proposal computes the thermal states
+constexpr int kTargetGroups = 4096;  // population mode: workgroups per likelihood launch worth splitting proposals for
 constexpr int kNCoef = 8;        // derived per-walker coefficients
 constexpr int kMaxDim = 16;      // max parameters per walker
 constexpr int kLdsTabMax = 3900; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)

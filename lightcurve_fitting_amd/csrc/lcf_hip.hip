@@ -1569,10 +1569,19 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
         s->ds.inline_finalize = 1;
         items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm, s->part};
+        // With many transients in one launch a single workgroup per proposal already fills the chip, and it stages
+        // the tables and reduces once for all of the proposal's chunks: fewer parts than the engine's default.
+        DevProblem& ip = items[t].pb;
+        const long long slots = (long long)n * s->ds.n_half;
+        const int want = (int)std::max<long long>(1, (kTargetGroups + slots - 1) / slots);
+        const int parts = std::min(ip.n_parts, want);
+        const int cpb = (ip.n_chunks + parts - 1) / parts;
+        ip.cpb = cpb;
+        ip.n_parts = (ip.n_chunks + cpb - 1) / cpb;
         lds = std::max(lds, s->e->lds_bytes);
         max_epochs = std::max(max_epochs, s->e->dp.n_epochs);
         max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
-        max_parts = std::max(max_parts, s->e->dp.n_parts);
+        max_parts = std::max(max_parts, items[t].pb.n_parts);
     }
     LCF_HIP(hipSetDevice(s0->e->device));
     MultiItem* ditems = nullptr;

@@ -197,6 +197,29 @@ def test_population_mode_equals_individual_runs():
     assert [list(partition(7, 3, r)) for r in range(3)] == [[0, 1, 2], [3, 4, 5], [6]]
 
 
+def test_large_population_regroups_partial_sums():
+    """With thousands of proposals in one launch population mode uses one workgroup per proposal instead of the
+    engine's several (fewer, longer partial chi^2 sums): log-probabilities agree with the solo runs to rounding and
+    the chains make the same decisions."""
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    problems, x0 = [], {}
+    for k in range(12):
+        pb = small_problem(npts=600 + k, seed=50 + k)
+        lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
+        problems.append((M.ShockCooling(redshift=0.), lc, priors))
+        x0[k] = pb['truth'] * (1 + 0.05 * np.random.default_rng(k).standard_normal((700, 5)))
+    pop = PopulationSampler(problems, 700, seed=7)
+    pop.run_mcmc(x0, 4)
+    for k in (0, 5, 11):
+        model, lc, pri = problems[k]
+        solo = EnsembleSampler(700, 5, model.engine_for(lc, priors=pri), seed=7 + k)
+        solo.run_mcmc(x0[k], 4)
+        np.testing.assert_allclose(pop[k].get_log_prob(), solo.get_log_prob(), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(pop[k].get_chain(), solo.get_chain(), rtol=1e-12)
+        assert np.array_equal(pop[k].acceptance_fraction, solo.acceptance_fraction)
+
+
 @pytest.mark.parametrize('nwalkers', [10, 22, 130])
 def test_odd_ensemble_sizes_match_oracle(nwalkers):
     """Walker counts that are not multiples of the wavefront or workgroup size (and the emcee minimum 2 ndim)."""
