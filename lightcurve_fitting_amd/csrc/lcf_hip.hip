@@ -220,7 +220,9 @@ __global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo
     points_body<VARIANT, MODE, LDS_TAB, THERM>(pb, blockIdx.x, w_lo, n_w, P, coef, lprior, therm, out0, out1);
 }
 
-// lnL (and log-posterior) per walker from the partial sums, fixed summation order.
+// lnL (and log-posterior) per walker from the partial sums, fixed summation order.  (A separate launch on purpose:
+// letting the last workgroup of a walker do this inside k_points needs an agent-scope fence per workgroup, which on
+// this part writes back and invalidates the XCD's L2 -- measured 3x slower k_points.)
 __global__ void k_finalize(const DevProblem pb, int n, const double* __restrict__ part,
                            const double* __restrict__ lprior, double* __restrict__ out) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,11 +413,28 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
                                  int do_thermal, double* __restrict__ coef, double* __restrict__ lprior,
                                  double2* __restrict__ therm) {
     __shared__ double sc[kNCoef + 1];
-    const int i = bid / n_echunks, ec = bid % n_echunks;
+    // Workgroup -> work item.  With thermal states the shard's slots come first, n_echunks workgroups each; every
+    // other slot (another rank's: commit + light proposal, wave-0 work only) gets ONE WAVE of the workgroups after
+    // them, so a rank with a small shard of a large ensemble does not pay a workgroup per foreign slot.
+    int i, ec, lane;
+    const int own_groups = do_thermal ? (hi - lo) * n_echunks : 0;
+    if (do_thermal && bid >= own_groups) {
+        const int k = (bid - own_groups) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+        i = k < lo ? k : k + (hi - lo);
+        ec = 0;
+        lane = threadIdx.x & 63;
+        if (i >= sm.n_half) return;
+    } else if (do_thermal) {
+        i = lo + bid / n_echunks;
+        ec = bid % n_echunks;
+        lane = threadIdx.x;
+    } else {
+        i = bid;
+        ec = 0;
+        lane = threadIdx.x;
+    }
     const bool mine = i >= lo && i < hi;       // this rank evaluates the likelihood of slot i
     const bool in_shard = do_thermal && mine;
-    if (ec > 0 && !in_shard) return;
-    const int lane = threadIdx.x;
     const int ep = ec * kBlock + lane;
     const double t_ep = (in_shard && ep < pb.n_epochs) ? pb.epoch_t[ep] : 0.;  // issued before the serial section
     const int prev_wid = (have_prev && ec == 0) ? prev_draws[i].wid : 0;
@@ -1141,13 +1160,14 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     const long long rel = g - s->g_run0;
     const DrawRec* draws = have_next ? s->d_draws + (size_t)rel * ds.n_half : nullptr;
     const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
-    // with several ranks most slots are other ranks' (light wave-0 work only): one-wave workgroups keep all of them
-    // resident at once, and the shard's thermal states get their own launch (launch_eval)
-    const bool sharded = lo > 0 || hi < ds.n_half;
-    const bool thermal = have_next && fuse_thermal && e->dp.use_therm && !sharded;
+    const bool thermal = have_next && fuse_thermal && e->dp.use_therm && hi > lo;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
-    // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then
-#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)(ds.n_half * nec)), dim3(thermal && e->dp.n_epochs > kFewEpochs ? kBlock : 64), 0, st, \
+    // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then; with it,
+    // foreign slots take one wave each of the workgroups behind the shard's (see step_body)
+    const int bdim = thermal && e->dp.n_epochs > kFewEpochs ? kBlock : 64;
+    const int foreign = ds.n_half - (hi - lo), wpg = bdim / 64;
+    const unsigned groups = thermal ? (unsigned)((hi - lo) * nec + (foreign + wpg - 1) / wpg) : (unsigned)ds.n_half;
+#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3(groups), dim3(bdim), 0, st, \
                                         e->dp, ds, have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, \
                                         nec, thermal ? 1 : 0, s->coef, s->lprior, s->therm)
     switch (ds.n_dim) {  // the fit dimensions of the supported models (+ sigma) get dedicated instantiations
@@ -1371,7 +1391,7 @@ lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int
     hipStream_t st = stream ? (hipStream_t)stream : s->e->stream;
     s->ds.inline_finalize = 0;
     if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-    const bool fused = s->e->dp.use_therm != 0 && lo == 0 && hi == s->ds.n_half;
+    const bool fused = s->e->dp.use_therm != 0;  // launch_next computed the shard's thermal states
     return launch_eval(s, lo, hi, fused, true, st);
 }
 
@@ -1489,7 +1509,7 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     LCF_HIP(hipEventRecord(s->ev0, st));
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
         if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-        const bool fused = s->e->dp.use_therm != 0 && c->n_ranks == 1;
+        const bool fused = s->e->dp.use_therm != 0;
         if (lcf_status r = launch_eval(s, lo, hi, fused, true, st)) return r;
         double* buf = s->ds.newlp[(s->g_next - 1) & 1];
         if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo, buf, (size_t)width, /*ncclDouble*/ 8, c->comm, st),
