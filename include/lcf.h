@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 2
+#define LCF_ABI_VERSION 3
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -30,7 +30,7 @@ typedef enum lcf_status {
     LCF_ERR_HIP = 2,              /* a HIP runtime call failed; see lcf_last_error() */
     LCF_ERR_NO_DEVICE = 3,        /* no usable GPU: this library has no CPU fallback */
     LCF_ERR_OUT_OF_MEMORY = 4,
-    LCF_ERR_UNSUPPORTED = 5,      /* e.g. ShockCooling3 (needs third-party extinction arithmetic) */
+    LCF_ERR_UNSUPPORTED = 5,      /* e.g. a reddened model whose band tables do not fit in LDS   */
     LCF_ERR_NAN_LOGPROB = 6,      /* sampler: a log-probability evaluated to NaN (emcee raises ValueError here) */
     LCF_ERR_STATE = 7             /* call sequence error (e.g. run before set_state) */
 } lcf_status;
@@ -39,6 +39,7 @@ typedef enum lcf_status {
 typedef enum lcf_model {
     LCF_MODEL_SHOCK_COOLING = 1,      /* ShockCooling          models.py:301-353  p = v_s, M_env, f_rho_M, R, t_0     */
     LCF_MODEL_SHOCK_COOLING2 = 2,     /* ShockCooling2         models.py:356-411  p = T_1, L_1, t_tr, t_0             */
+    LCF_MODEL_SHOCK_COOLING3 = 3,     /* ShockCooling3         models.py:433-496  p = v_s,M_env,f_rho_M,R,d_L,E(B-V),t_0 */
     LCF_MODEL_SHOCK_COOLING4 = 4,     /* ShockCooling4         models.py:507-632  p = v_s, M_env, f_rho_M, R, t_0     */
     LCF_MODEL_COMPANION_SHOCKING = 5, /* CompanionShocking     models.py:848-918  p = t_0,a,Mv7,t_max,s,r_r,r_i,r_U   */
     LCF_MODEL_COMPANION_SHOCKING2 = 6,/* CompanionShocking2    models.py:921-980  p = t_0,a,Mv7,t_max,s,dt_U,dt_i     */
@@ -92,6 +93,10 @@ typedef struct lcf_problem {
     const int32_t* tab_off;   /* [n_filters + 1] */
     const double* tab_a;      /* [tab_off[n_filters]] */
     const double* tab_w;      /* [tab_off[n_filters]] */
+    /* Reddening, LCF_MODEL_SHOCK_COOLING3 only (NULL otherwise): A_lambda / E(B-V) of the extinction law at every
+     * table sample, so that sample k is weighted by 10^(-0.4 E(B-V) tab_ext[k]) per walker
+     * (filters.py:32-33, 308-310: extinction_law(freq, ebv) inside Filter.synthesize). */
+    const double* tab_ext;    /* [tab_off[n_filters]] */
     /* Optional compressed companions (all NULL = none): per filter a shorter table (the Gauss quadrature of the full
      * table's own discrete measure, computed by the host packer) that reproduces the band sum to 2e-14 for every
      * temperature T >= ctab_tmin[i]; the engine switches per data point and uses the full table below it. */

@@ -23,10 +23,13 @@ constexpr double kTwoPi = 6.283185307179586;
 // Above this temperature [kK] a_k/T < 1e-13 and the reference's exp(x) - 1 is pure cancellation noise (and 0 beyond
 // 1e17 kK); the engine returns a zero band integral there.  Physical fits stay below 1e3 kK.
 constexpr double kTmax = 1e15;
+// 1 / (4 pi Mpc^2) in m^-2 (models.py:12), Mpc = 1e6 * 648000 / pi au
+constexpr double kC4 = 8.357743635931361e-47;
 
 enum Model : int {
     kShockCooling = 1,
     kShockCooling2 = 2,
+    kShockCooling3 = 3,
     kShockCooling4 = 4,
     kCompanion = 5,
     kCompanion2 = 6,
@@ -63,6 +66,7 @@ struct DevProblem {
     const double* epoch_t; // [n_epochs]
     const double* exp2tab;   // 2^(j/256), j = 0..255
     const double2* tab;  // (a_k, W_k)
+    const double* tab_ext;  // ShockCooling3: 0.4 log2(10) A_k / E(B-V) per table sample (0 for padding), else null
     const int* f_kpar;
     const int* f_spar;
     const int* f_dtpar;
@@ -207,10 +211,17 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
     const double* k = pb.consts;
     for (int i = 0; i < kNCoef; ++i) c[i] = 0.;
     switch (pb.model) {
-        case kShockCooling: {  // models.py:260-267
+        case kShockCooling:
+        case kShockCooling3: {  // models.py:260-267; ShockCooling3 (models.py:493-495): + distance and reddening
             const double A = k[0], a = k[1], alpha = k[2], eps1 = k[3], eps2 = k[4], L0 = k[5], T0 = k[6], ratio = k[7];
             const double v = p[0], M = p[1], f = p[2], R = p[3];
-            c[0] = p[4];
+            if (pb.model == kShockCooling3) {
+                c[0] = p[6];
+                c[5] = kC4 / (p[4] * p[4]);  // flux = c4 * lum / dist ** 2
+                c[6] = p[5];                 // E(B-V): scales the band-table weights (points_body)
+            } else {
+                c[0] = p[4];
+            }
             if (v > 0. && M > 0. && f > 0. && R > 0. && v < 1e100 && M < 1e100 && f < 1e100 && R < 1e100) {
                 // all bases positive: every power() is a plain power; share the four logarithms
                 const double lv = lq[0], lM = lq[1], lf = lq[2], lR = lq[3];
@@ -339,7 +350,8 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
     pref = 0.;
     switch (pb.model) {
         case kShockCooling:
-        case kShockCooling2: {
+        case kShockCooling2:
+        case kShockCooling3: {
             const double eps1 = k[3], eps2 = k[4], alpha = k[2];
             if (t > 0.) {
                 const double lt = log(t);

@@ -85,6 +85,7 @@ __device__ inline double point_model(const DevProblem& pb, const double* __restr
     }
     // pref may be NaN (propagates) or 0 with 1/T == 0.
     double yfit = (pref != pref) ? pref : pref * S;
+    if (pb.model == kShockCooling3) yfit *= c[5];  // models.py:495
     if (pb.model >= kCompanion && pb.model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
         const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
         const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
@@ -134,8 +135,18 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
 
     if (VARIANT == 1 && tid < kExpTabSize) exptab[tid] = pb.exp2tab[tid];
-    if (LDS_TAB)
-        for (int k = tid; k < pb.n_tab; k += kBlock) ltab[k] = pb.tab[k];
+    if (LDS_TAB) {
+        if (pb.model == kShockCooling3) {  // this walker's reddening goes into the staged weights
+            const double ebv = coef[(size_t)w * kNCoef + 6];
+            for (int k = tid; k < pb.n_tab; k += kBlock) {
+                double2 aw = pb.tab[k];
+                aw.y *= exp2(-ebv * pb.tab_ext[k]);
+                ltab[k] = aw;
+            }
+        } else {
+            for (int k = tid; k < pb.n_tab; k += kBlock) ltab[k] = pb.tab[k];
+        }
+    }
     __syncthreads();
 
     const double* c = coef + (size_t)w * kNCoef;   // wave-uniform -> scalar loads
@@ -770,14 +781,15 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     *out = nullptr;
     if (pr->abi_version != LCF_ABI_VERSION) return fail(LCF_ERR_INVALID_ARGUMENT, "abi_version mismatch");
     switch (pr->model) {
-        case LCF_MODEL_SHOCK_COOLING: case LCF_MODEL_SHOCK_COOLING2: case LCF_MODEL_SHOCK_COOLING4:
+        case LCF_MODEL_SHOCK_COOLING: case LCF_MODEL_SHOCK_COOLING2: case LCF_MODEL_SHOCK_COOLING3:
+        case LCF_MODEL_SHOCK_COOLING4:
         case LCF_MODEL_COMPANION_SHOCKING: case LCF_MODEL_COMPANION_SHOCKING2: case LCF_MODEL_COMPANION_SHOCKING3:
         case LCF_MODEL_BLACKBODY:
             break;
         default:
             return fail(LCF_ERR_UNSUPPORTED, "unknown or unsupported model id");
     }
-    static const int kNPar[9] = {0, 5, 4, 0, 5, 8, 7, 7, 2};
+    static const int kNPar[9] = {0, 5, 4, 7, 5, 8, 7, 7, 2};
     if (pr->n_par != kNPar[pr->model]) return fail(LCF_ERR_INVALID_ARGUMENT, "n_par does not match the model");
     const int n_dim = pr->n_par + (pr->use_sigma ? 1 : 0);
     if (n_dim > kMaxDim) return fail(LCF_ERR_INVALID_ARGUMENT, "too many parameters");
@@ -786,6 +798,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     if (pr->n_points > 0 && (!pr->t || !pr->y || !pr->dy || !pr->filt_idx))
         return fail(LCF_ERR_INVALID_ARGUMENT, "null photometry");
     if (!pr->tab_off || !pr->tab_a || !pr->tab_w) return fail(LCF_ERR_INVALID_ARGUMENT, "null band tables");
+    const bool reddened = pr->model == LCF_MODEL_SHOCK_COOLING3;
+    if (reddened && !pr->tab_ext) return fail(LCF_ERR_INVALID_ARGUMENT, "ShockCooling3 needs tab_ext");
     if (pr->sigma_type != LCF_SIGMA_RELATIVE && pr->sigma_type != LCF_SIGMA_ABSOLUTE)
         return fail(LCF_ERR_INVALID_ARGUMENT, "sigma_type must be relative or absolute");
     const int N = (int)pr->n_points, NF = pr->n_filters;
@@ -830,7 +844,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     int64_t samples = 0;
     // device table: per filter [full | compressed], each padded to a multiple of four samples with zero weights
     // (exactly 0 contribution)
-    const bool have_ctab = pr->ctab_off && pr->ctab_a && pr->ctab_w && pr->ctab_tmin;
+    // (a reddened model reweights the samples per walker: the compressed tables do not apply)
+    const bool have_ctab = pr->ctab_off && pr->ctab_a && pr->ctab_w && pr->ctab_tmin && !reddened;
     if (have_ctab) {
         if (pr->ctab_off[0] != 0) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off[0] must be 0"));
         for (int f = 0; f < NF; ++f)
@@ -840,14 +855,22 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<int> pfull(2 * NF, 0), pcomp(2 * NF, 0);  // (offset, count) pairs
     std::vector<double> ptmin(NF, INFINITY);
     std::vector<double2> htab;
+    std::vector<double> hext;  // reddened models: 0.4 log2(10) A_k / E(B-V), aligned with htab
     auto append = [&](const double* a, const double* w, int k0, int k1, int* slot) -> bool {
         slot[0] = (int)htab.size();
         for (int k = k0; k < k1; ++k) {
             if (!(a[k] > 0.) || !std::isfinite(a[k]) || !std::isfinite(w[k])) return false;
             htab.push_back(make_double2(a[k], w[k]));
+            if (reddened) {
+                if (!std::isfinite(pr->tab_ext[k])) return false;
+                hext.push_back(0.4 * 3.321928094887362 * pr->tab_ext[k]);
+            }
         }
         const double apad = k1 > k0 ? a[k1 - 1] : 1.;
-        while ((htab.size() - slot[0]) % 4) htab.push_back(make_double2(apad, 0.));
+        while ((htab.size() - slot[0]) % 4) {
+            htab.push_back(make_double2(apad, 0.));
+            if (reddened) hext.push_back(0.);
+        }
         slot[1] = (int)htab.size() - slot[0];
         return true;
     };
@@ -924,6 +947,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
     dp.tab_in_lds = (int)htab.size() <= kLdsTabMax;
+    if (reddened && !dp.tab_in_lds)
+        return bail(fail(LCF_ERR_UNSUPPORTED, "ShockCooling3: the band tables must fit in LDS"));
     dp.n_epochs = (int)epochs.size();
     dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
     dp.variant = 1;
@@ -942,6 +967,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
     UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hfilt, dfilt); UP(horig, dorig);
     UP(htab, dtab); UP(htaboff, e->d_tab_off);
+    if (reddened) {
+        double* dext;
+        UP(hext, dext);
+        dp.tab_ext = dext;
+    }
     int* depoch;
     int4* ddesc;
     double *dexp, *depocht, *dinvdy, *dinvtmin;

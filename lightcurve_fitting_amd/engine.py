@@ -11,11 +11,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 2
+LCF_ABI_VERSION = 3
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
 MODEL_SHOCK_COOLING2 = 2
+MODEL_SHOCK_COOLING3 = 3
 MODEL_SHOCK_COOLING4 = 4
 MODEL_COMPANION_SHOCKING = 5
 MODEL_COMPANION_SHOCKING2 = 6
@@ -43,7 +44,7 @@ class LcfProblem(C.Structure):
                 ('sigma_type', C.c_int32), ('n_filters', C.c_int32), ('n_points', C.c_int64),
                 ('consts', C.c_double * N_CONSTS),
                 ('t', _dp), ('y', _dp), ('dy', _dp), ('filt_idx', _ip), ('tab_off', _ip), ('tab_a', _dp),
-                ('tab_w', _dp), ('ctab_off', _ip), ('ctab_a', _dp), ('ctab_w', _dp), ('ctab_tmin', _dp),
+                ('tab_w', _dp), ('tab_ext', _dp), ('ctab_off', _ip), ('ctab_a', _dp), ('ctab_w', _dp), ('ctab_tmin', _dp),
                 ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
                 ('n_knots', C.c_int32), ('reserved', C.c_int32), ('spline_knots', _dp), ('spline_coef', _dp),
                 ('priors', C.POINTER(LcfPrior))]
@@ -160,7 +161,7 @@ class Engine:
     ``(kind, p_min, p_max, mean, stddev)`` or ``None``."""
 
     def __init__(self, model_id, n_par, consts, t, y, dy, filt_idx, tab_off, tab_a, tab_w, use_sigma=False,
-                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None):
+                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None, tab_ext=None):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -180,6 +181,12 @@ class Engine:
         pr.t, pr.y, pr.dy = _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2])
         pr.filt_idx, pr.tab_off = _ptr(keep[3], _ip), _ptr(keep[4], _ip)
         pr.tab_a, pr.tab_w = _ptr(keep[5]), _ptr(keep[6])
+        if tab_ext is not None:  # A_lambda / E(B-V) per table sample (ShockCooling3)
+            ext = _f64(tab_ext)
+            if len(ext) != len(keep[5]):
+                raise ValueError('tab_ext must have one entry per table sample')
+            keep.append(ext)
+            pr.tab_ext = _ptr(ext)
         if ctab is not None:  # (coff, ca, cw, ctmin): Gauss-compressed companions of the band tables
             cx = [_i32(ctab[0]), _f64(ctab[1]), _f64(ctab[2]), _f64(ctab[3])]
             if len(cx[0]) != pr.n_filters + 1 or len(cx[3]) != pr.n_filters or len(cx[1]) != len(cx[2]):

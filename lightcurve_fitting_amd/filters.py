@@ -213,6 +213,26 @@ class Filter:
             a, w = a[keep], w[keep]
         return np.ascontiguousarray(a), np.ascontiguousarray(w)
 
+    def extinction_table(self, z=0., cutoff_freq=np.inf, drop_zeros=True, rv=3.1):
+        """``A(lambda_k) / E(B-V)`` of the Fitzpatrick (1999) law at the emitted-frame wavelength of every sample
+        :meth:`planck_table` returns (same order, same dropped rows): ``Filter.synthesize`` multiplies the spectrum
+        by ``10 ** (-0.4 E(B-V) e_k)`` sample by sample (``filters.py:32-33, 308-310``)."""
+        from .extinction import a_lambda_per_ebv
+        nu = self.freq * (1. + z)
+        e = a_lambda_per_ebv(c / nu, rv)
+        if drop_zeros:
+            w = nu ** 3 * np.minimum(1., cutoff_freq / nu) * self._get('tw') * self.T_norm_per_freq
+            e = e[w != 0.]
+        return np.ascontiguousarray(e)
+
+    def extinction(self, ebv, rv=3.1, z=0.):
+        """Extinction ``A_lambda`` [mag] at this filter's effective wavelength (``filters.py:267-286``); ``None``
+        for a filter without a transmission table."""
+        from .extinction import fitzpatrick99
+        if self.wl_eff is None:
+            return None
+        return fitzpatrick99(np.array([self.wl_eff * 10. / (1. + z)]), ebv * rv, rv)[0]
+
     # --- identity ---------------------------------------------------------
     def __str__(self):
         return self.name
@@ -314,16 +334,20 @@ def as_filter(f):
 class PackedTables:
     """Concatenated ``(a_k, W_k)`` tables for a list of distinct filters (CSR layout: ``off[i]:off[i+1]``)."""
 
-    def __init__(self, filters, z=0., cutoff_freq=np.inf, drop_zeros=True, compress=True):
+    def __init__(self, filters, z=0., cutoff_freq=np.inf, drop_zeros=True, compress=True, reddening=False, rv=3.1):
         self.filters = [as_filter(f) for f in filters]
-        a_parts, w_parts, off = [], [], [0]
+        a_parts, w_parts, e_parts, off = [], [], [], [0]
         for f in self.filters:
             a, w = f.planck_table(z, cutoff_freq, drop_zeros)
             a_parts.append(a)
             w_parts.append(w)
+            if reddening:
+                e_parts.append(f.extinction_table(z, cutoff_freq, drop_zeros, rv))
             off.append(off[-1] + len(a))
         self.a = np.concatenate(a_parts) if a_parts else np.zeros(0)
         self.w = np.concatenate(w_parts) if w_parts else np.zeros(0)
+        #: A_lambda / E(B-V) per sample (models with E(B-V) as a parameter), else None
+        self.ext = (np.concatenate(e_parts) if e_parts else np.zeros(0)) if reddening else None
         self.off = np.asarray(off, dtype=np.int32)
         self.z = z
         self.cutoff_freq = cutoff_freq

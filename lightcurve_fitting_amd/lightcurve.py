@@ -6,9 +6,8 @@ store (dict of NumPy arrays + ``meta``) exposing the part of the reference's ``L
 ``LC.read``, ``lc[col]``, ``lc.colnames``, ``lc.meta``, ``where``, ``filters_to_objects``, ``zp``, ``calcAbsMag``,
 ``calcLum``, ``calcFlux`` and the free functions ``mag2flux`` / ``flux2mag``.
 
-Not reproduced: plotting, binning, the Planck18 distance modulus (pass ``dm``) and Fitzpatrick-99 extinction at
-the filters' effective wavelengths (third-party arithmetic, parity unpinned): pass per-filter ``extinction`` /
-``hostext`` dictionaries, or leave E(B-V) at 0.
+Not reproduced: plotting, binning and the Planck18 distance modulus (pass ``dm``).  E(B-V)-based extinction uses
+``extinction.py`` (the Fitzpatrick 1999 law restated; third-party arithmetic for the reference).
 """
 import numpy as np
 
@@ -207,8 +206,8 @@ class LC:
 
     def calcAbsMag(self, dm=None, extinction=None, hostext=None, ebv=None, rv=None, host_ebv=None, host_rv=None,
                    redshift=None):
-        """``'absmag'`` from ``'mag'``: distance modulus and per-filter extinction coefficients
-        (lightcurve.py:271-345).  E(B-V)-based extinction needs the third-party Fitzpatrick-99 law: not available."""
+        """``'absmag'`` from ``'mag'``: distance modulus and per-filter extinction coefficients, given or computed
+        from E(B-V) and R_V at each filter's effective wavelength (lightcurve.py:271-345)."""
         if redshift is not None:
             self.meta['redshift'] = redshift
         elif 'redshift' not in self.meta:
@@ -223,16 +222,20 @@ class LC:
             ebv = self.meta.get('ebv')
         if host_ebv is None:
             host_ebv = self.meta.get('host_ebv')
-        if (ebv and extinction is None and 'extinction' not in self.meta) or \
-                (host_ebv and hostext is None and 'hostext' not in self.meta):
-            raise NotImplementedError('E(B-V) -> A_lambda needs the Fitzpatrick-99 law (third-party, unpinned): '
-                                      'pass per-filter extinction / hostext dictionaries')
+        if rv is None:
+            rv = self.meta.get('rv', 3.1)
+        if host_rv is None:
+            host_rv = self.meta.get('host_rv', 3.1)
+        with_table = [f for f in set(self['filter']) if f.wl_eff is not None]
         if extinction is not None:
             self.meta['extinction'] = extinction
-        self.meta.setdefault('extinction', {})
+        elif 'extinction' not in self.meta:
+            self.meta['extinction'] = {} if ebv is None else {f.name: f.extinction(ebv, rv) for f in with_table}
         if hostext is not None:
             self.meta['hostext'] = hostext
-        self.meta.setdefault('hostext', {})
+        elif 'hostext' not in self.meta:  # the reference reads the host redshift from meta['z'] here (:330)
+            self.meta['hostext'] = {} if host_ebv is None else {
+                f.name: f.extinction(host_ebv, host_rv, self.meta.get('z', 0.)) for f in with_table}
         absmag = np.asarray(self['mag'], dtype=float) - self.meta['dm']
         filt_col = self['filter']
         for filtobj in set(filt_col):

@@ -20,6 +20,7 @@ Extension over the reference: ``p`` may be a C-contiguous ``(n, ndim)`` block (w
 import numpy as np
 
 from . import engine as _eng
+from .spline import not_a_knot_coefficients  # noqa: F401  (re-exported)
 from .filters import Filter, PackedTables, as_filter, filtdict, _tables
 
 # module-level constants with the reference's names (models.py:10-12, 1101-1102)
@@ -112,37 +113,6 @@ def _index_filters(filts):
     return uniq, np.array([lookup[f] for f in filts], dtype=np.int32)
 
 
-def not_a_knot_coefficients(x, y):
-    """Piecewise-cubic coefficients ``c[i] = (c3, c2, c1, c0)`` of the C2 interpolant with not-a-knot ends:
-    ``S(u) = c3 (u-x_i)^3 + c2 (u-x_i)^2 + c1 (u-x_i) + c0`` on ``[x_i, x_{i+1}]``.
-
-    This is the interpolant SciPy's ``CubicSpline`` builds by default, which the reference uses for the SiFTO
-    template (models.py:717).  Solved here as a dense (n x n) system for the knot derivatives."""
-    x = np.asarray(x, dtype=np.float64)
-    y = np.asarray(y, dtype=np.float64)
-    n = len(x)
-    if n < 4:
-        raise ValueError('need at least 4 knots')
-    dx = np.diff(x)
-    slope = np.diff(y) / dx
-    A = np.zeros((n, n))
-    b = np.zeros(n)
-    for i in range(1, n - 1):  # continuity of the second derivative at interior knots
-        A[i, i - 1] = dx[i]
-        A[i, i] = 2. * (dx[i - 1] + dx[i])
-        A[i, i + 1] = dx[i - 1]
-        b[i] = 3. * (dx[i] * slope[i - 1] + dx[i - 1] * slope[i])
-    d = x[2] - x[0]  # third derivative continuous across x_1
-    A[0, 0], A[0, 1] = dx[1], d
-    b[0] = ((dx[0] + 2. * d) * dx[1] * slope[0] + dx[0] ** 2 * slope[1]) / d
-    d = x[-1] - x[-3]  # ... and across x_{n-2}
-    A[-1, -1], A[-1, -2] = dx[-2], d
-    b[-1] = (dx[-1] ** 2 * slope[-2] + (2. * d + dx[-1]) * dx[-2] * slope[-1]) / d
-    s = np.linalg.solve(A, b)
-    tq = (s[:-1] + s[1:] - 2. * slope) / dx
-    return np.column_stack([tq / dx, (slope - s[:-1]) / dx - tq, s[:-1], y[:-1]])
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # models
 # ---------------------------------------------------------------------------------------------------------------
@@ -153,6 +123,8 @@ class Model:
     units = []
     output_quantity = 'lum'
     model_id = None
+    #: E(B-V) is a model parameter: band-table weights are reddened per walker (full tables only)
+    reddened = False
 
     def __init__(self, lc=None, redshift=0.):
         if redshift:
@@ -204,12 +176,13 @@ class Model:
             raise Exception('sigma_type must either be "relative" or "absolute"')
         filts = [as_filter(f) for f in filts]
         uniq, idx = _index_filters(filts)
-        tabs = PackedTables(uniq, z=self.z)
+        tabs = PackedTables(uniq, z=self.z, compress=not self.reddened, reddening=self.reddened)
         pri = None if priors is None else [p.descriptor() for p in priors]
         return _eng.Engine(self.model_id, self.n_model_params, self._consts(), t, y, dy, idx, tabs.off, tabs.a, tabs.w,
                            use_sigma=use_sigma, sigma_type=st, priors=pri,
                            companion=self._companion_tables(uniq), device=self.device if device is None else device,
-                           ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
+                           ctab=None if self.reddened else (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
+                           tab_ext=tabs.ext)
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):
         """Engine bound to ``lc`` (cached per light-curve object, sigma mode and prior set)."""
@@ -235,13 +208,14 @@ class Model:
         out = eng.log_likelihood(p)
         return float(out[0]) if p.ndim == 1 else out
 
-    def _eval_engine(self, t_in, f):
-        """Engine for model evaluation at (t, f): pointwise when the lengths agree (models.py:1161), else the dense
-        filters x times grid (models.py:1163-1164).  Returns (engine, grid_shape or None)."""
+    def _eval_engine(self, t_in, f, scalar_params=True):
+        """Engine for model evaluation at (t, f): pointwise when the lengths agree and the parameters are scalars
+        (``T.ndim == 1 and len(T) == len(filters)``, models.py:1161), else the dense filters x times grid
+        (models.py:1163-1164).  Returns (engine, grid_shape or None)."""
         t_in = np.atleast_1d(np.asarray(t_in, dtype=np.float64))
         single = isinstance(f, (Filter, str))
         filts = [as_filter(f)] if single else [as_filter(x) for x in f]
-        if not single and t_in.ndim == 1 and len(t_in) == len(filts):
+        if not single and scalar_params and t_in.ndim == 1 and len(t_in) == len(filts):
             t, fl, shape = t_in, filts, None
         else:
             t = np.tile(t_in.ravel(), len(filts))
@@ -257,13 +231,14 @@ class Model:
         return eng, shape
 
     def evaluate(self, t_in, f, *params):
-        """Model light curve(s).  Scalar parameters -> (npoints,) [pointwise] or (nfilters, ntimes) [grid];
-        array parameters of length n -> an extra trailing axis of length n."""
+        """Model light curve(s).  Scalar parameters -> (npoints,) [pointwise, when ``len(t_in) == len(f)``] or
+        (nfilters, ntimes) [grid]; array parameters of length n -> the grid with a trailing axis of length n, as in
+        the reference (whose pointwise branch needs a one-dimensional temperature)."""
         if len(params) != self.n_model_params:
             raise TypeError(f'{type(self).__name__} takes {self.n_model_params} parameters, got {len(params)}')
-        eng, shape = self._eval_engine(t_in, f)
         cols = np.broadcast_arrays(*[np.asarray(x, dtype=np.float64) for x in params])
         scalar = cols[0].ndim == 0
+        eng, shape = self._eval_engine(t_in, f, scalar)
         P = np.column_stack([np.atleast_1d(c).ravel() for c in cols])
         y = eng.evaluate(P)  # (n, npoints)
         y = y[0] if scalar else y.T
@@ -357,12 +332,28 @@ class ShockCooling2(BaseShockCooling):
 
 
 class ShockCooling3(BaseShockCooling):
-    """Distance and reddening as free parameters (models.py:433-504).  Needs the third-party Fitzpatrick-99
-    arithmetic of the ``extinction`` package, whose parity is unpinned: not available in this engine."""
+    """``ShockCooling`` with the luminosity distance d_L [Mpc] and the reddening E(B-V) as free parameters; fits
+    ``'flux'`` instead of ``'lum'`` (models.py:433-504): ``flux = c4 * Lnu(E(B-V)) / d_L ** 2``, the blackbody being
+    reddened sample by sample inside the band integral with the Fitzpatrick (1999) law, R_V = 3.1
+    (``extinction.py``; that law is third-party arithmetic for the reference -- see its header for how it is pinned)."""
+    model_id = _eng.MODEL_SHOCK_COOLING3
+    input_names = ['v_\\mathrm{s*}', 'M_\\mathrm{env}', 'f_\\rho M', 'R', 'd_L', 'E(B-V)', 't_0']
+    units = ['10^8.5 cm/s', 'Msun', 'Msun', '10^13 cm', 'Mpc', 'mag', 'd']
+    output_quantity = 'flux'
+    reddened = True
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('ShockCooling3 needs E(B-V) != 0 band integrals (third-party extinction law); '
-                                  'it is outside the MI355X hot path')
+    def temperature_radius(self, t_in, v_s, M_env, f_rho_M, R, t_exp=0.):
+        """Same (T, R) as ``ShockCooling`` (``BaseShockCooling.temperature_radius``, models.py:231-269)."""
+        one = np.ones_like(np.asarray(v_s, dtype=np.float64))
+        return super().temperature_radius(t_in, v_s, M_env, f_rho_M, R, one, 0. * one, t_exp * one)
+
+    @staticmethod
+    def t_min(p, kappa=1.):
+        return BaseShockCooling.t_min([p[0], p[1], p[2], p[3], p[6] if len(p) > 6 else 0.], kappa=kappa)
+
+    @staticmethod
+    def t_max(p, kappa=1.):
+        return BaseShockCooling.t_max([p[0], p[1], p[2], p[3], p[6] if len(p) > 6 else 0.], kappa=kappa)
 
 
 class ShockCooling4(Model):
@@ -487,23 +478,34 @@ class Blackbody(Model):
     input_names = ['T', 'R']
     units = ['kK', '1000 Rsun']
 
+    def _eval_engine(self, t_in, f, scalar_params=True):
+        # not a reference Model: one (filter, time) point per entry even for arrays of candidates, result (npoints, n)
+        return super()._eval_engine(t_in, f, True)
+
 
 def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0.):
-    """Band-averaged L_nu of blackbodies through filters (models.py:1131-1165), E(B-V) = 0 only.
+    """Band-averaged L_nu of blackbodies through filters (models.py:1131-1165).
 
     Pointwise when ``T`` is 1-D with one entry per filter, else every filter for every (T, R): result shape
-    ``(nfilters,) + T.shape``."""
-    if np.any(np.asarray(ebv) != 0.):
-        raise NotImplementedError('E(B-V) != 0 needs the third-party extinction law')
+    ``(nfilters,) + T.shape``.  ``ebv``: one E(B-V) for the whole call (the reddening goes into the table weights at
+    pack time); per-walker reddening inside a fit is ``ShockCooling3``'s job."""
+    if np.ndim(ebv) != 0:
+        raise NotImplementedError('blackbody_to_filters takes one scalar E(B-V) per call')
     T = np.array(T, dtype=np.float64)
     R = np.array(R, dtype=np.float64)
     if T.shape != R.shape:
         raise Exception('T & R must have the same shape')
     filts = [as_filter(f) for f in (filters if not isinstance(filters, (Filter, str)) else [filters])]
     uniq, idx = _index_filters(filts)
-    tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
+    if ebv:
+        tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq, compress=False, reddening=True)
+        tabs.w = tabs.w * 10. ** (-0.4 * float(ebv) * tabs.ext)
+        ctab = None
+    else:
+        tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
+        ctab = (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin)
     eng = _eng.Engine(_eng.MODEL_BLACKBODY, 2, [], np.zeros(1), np.zeros(1), np.ones(1), np.zeros(1, dtype=np.int32),
-                      tabs.off, tabs.a, tabs.w, ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
+                      tabs.off, tabs.a, tabs.w, ctab=ctab)
     try:
         if T.ndim == 1 and len(T) == len(filts):
             return eng.blackbody_to_filters(idx, T, R)

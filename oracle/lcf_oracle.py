@@ -8,8 +8,10 @@ the ``cpu_baseline`` leg of ``bench.py`` may use it.
 Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against golden vectors that
 ``tools/refgen/make_golden.py`` produced by running the reference's own ``models.py``/``filters.py`` on the build
 host (under unit/table stand-ins for the absent astropy package), and against the known answers KA-1..KA-8 of
-SURVEY.md section 8c.  Third-party arithmetic that is NOT pinned: the ``extinction`` package (E(B-V) != 0) and
-emcee's RNG stream (the stretch move below follows emcee's published algorithm with its own counter-based RNG).
+SURVEY.md section 8c.  Third-party arithmetic that cannot be pinned by execution here: the ``extinction`` package
+(E(B-V) != 0, ShockCooling3 only: ``fitzpatrick99`` below restates the published law and is checked against the one
+known answer that package's README prints) and emcee's RNG stream (the stretch move below follows emcee's
+published algorithm with its own counter-based RNG).
 
 Each function cites the reference lines it follows.
 """
@@ -103,18 +105,53 @@ def planck(nu, T, R, cutoff_freq=np.inf):
         return C2 * prefac * occupation
 
 
-def synthesize_blackbody(b, T, R, z=0., cutoff_freq=np.inf):
-    """Band-averaged L_nu of a blackbody.  filters.py:288-310 with ebv = 0 (extinction factor exactly 1)."""
+def fitzpatrick99(wave, a_v, r_v=3.1):
+    """Fitzpatrick (1999) extinction A(lambda) [mag], ``wave`` in angstrom: the published law as the third-party
+    ``extinction`` package codes it (called at filters.py:32, :286).  Ultraviolet (< 2700 A): Fitzpatrick & Massa
+    (1990) parametrisation; optical/IR: natural cubic spline through nine anchors in 1/lambda."""
+    x = 1e4 / np.asarray(wave, dtype=np.float64)
+    c2 = -0.824 + 4.717 / r_v
+    c1 = 2.030 - 3.007 * c2
+
+    def k_uv(xx):
+        d = xx ** 2 / ((xx ** 2 - 4.596 ** 2) ** 2 + xx ** 2 * 0.99 ** 2)
+        y = np.maximum(xx - 5.9, 0.)
+        return c1 + c2 * xx + 3.23 * d + 0.41 * (0.5392 * y ** 2 + 0.05644 * y ** 3)
+
+    xk = 1e4 / np.array([np.inf, 26500., 12200., 6000., 5470., 4670., 4110., 2700., 2600.])
+    yk = np.array([-r_v, 0.26469 * r_v / 3.1 - r_v, 0.82925 * r_v / 3.1 - r_v,
+                   -0.422809 + 1.00270 * r_v + 2.13572e-04 * r_v ** 2 - r_v,
+                   -5.13540e-02 + 1.00216 * r_v - 7.35778e-05 * r_v ** 2 - r_v,
+                   0.700127 + 1.00184 * r_v - 3.32598e-05 * r_v ** 2 - r_v,
+                   1.19456 + 1.01707 * r_v - 5.46959e-03 * r_v ** 2 + 7.97809e-04 * r_v ** 3
+                   - 4.45636e-05 * r_v ** 4 - r_v, 0., 0.])
+    yk[7:] = k_uv(xk[7:])
+    k = np.where(x >= 1e4 / 2700., k_uv(x), CubicSpline(xk, yk, bc_type='natural')(np.minimum(x, xk[-1])))
+    return a_v * (1. + k / r_v)
+
+
+def extinction_law(freq, ebv, rv=3.1):
+    """Extinction factor 10**(A/-2.5) at emitted-frame frequencies ``freq`` [THz]; shape ``ebv.shape + freq.shape``.
+    filters.py:14-33"""
+    a_per_ebv = fitzpatrick99(C_NM_THZ * 10. / np.asarray(freq, dtype=np.float64), rv, rv)
+    return 10. ** (np.multiply.outer(np.asarray(ebv, dtype=np.float64), a_per_ebv) / -2.5)
+
+
+def synthesize_blackbody(b, T, R, z=0., cutoff_freq=np.inf, ebv=None):
+    """Band-averaged L_nu of a blackbody.  filters.py:288-310; ``ebv=None`` is E(B-V) = 0 (extinction factor
+    exactly 1).  ``ebv`` must broadcast against the trailing axes of ``T``."""
     freq = b.freq * (1. + z)
-    return _trapz(planck(freq, T, R, cutoff_freq) * b.tnorm, b.freq)
+    if ebv is None:
+        return _trapz(planck(freq, T, R, cutoff_freq) * b.tnorm, b.freq)
+    return _trapz(planck(freq, T, R, cutoff_freq) * extinction_law(freq, ebv) * b.tnorm, b.freq)
 
 
-def blackbody_to_filters_pointwise(bands, T, R, z=0., cutoff_freq=np.inf):
+def blackbody_to_filters_pointwise(bands, T, R, z=0., cutoff_freq=np.inf, ebv=None):
     """Reference-shaped pointwise branch: one Python-level band integral per data point.  models.py:1161-1162"""
-    return np.array([synthesize_blackbody(b, t, r, z, cutoff_freq) for b, t, r in zip(bands, T, R)])
+    return np.array([synthesize_blackbody(b, t, r, z, cutoff_freq, ebv) for b, t, r in zip(bands, T, R)])
 
 
-def blackbody_to_filters_batch(bands, T, R, z=0., cutoff_freq=np.inf):
+def blackbody_to_filters_batch(bands, T, R, z=0., cutoff_freq=np.inf, ebv=None):
     """Same numbers as the pointwise branch for ``T, R`` of shape (npoints, ...): grouped by band so that each band
     is integrated for all of its points (and all walkers) at once."""
     T = np.asarray(T, dtype=np.float64)
@@ -125,7 +162,7 @@ def blackbody_to_filters_batch(bands, T, R, z=0., cutoff_freq=np.inf):
     names = np.array([b.name for b in bands])
     for nm in dict.fromkeys(names.tolist()):
         sel = np.nonzero(names == nm)[0]
-        out[sel] = synthesize_blackbody(band(nm), T[sel], R[sel], z, cutoff_freq)
+        out[sel] = synthesize_blackbody(band(nm), T[sel], R[sel], z, cutoff_freq, ebv)
     return out
 
 
@@ -292,6 +329,10 @@ def evaluate(model, t, bands, p, reference_shaped=False):
     if kind == 'ShockCooling2':  # models.py:403-407
         T, R = orc.temperature_radius2(t, *p)
         return bb(bands, T, R, orc.z)
+    if kind == 'ShockCooling3':  # models.py:493-496: p = v_s, M_env, f_rho_M, R, dist, ebv, t_exp
+        T, R = orc.temperature_radius(t, p[0], p[1], p[2], p[3], p[6])
+        with np.errstate(all='ignore'):
+            return C4 * bb(bands, T, R, orc.z, ebv=p[5]) / p[4] ** 2.
     if kind == 'ShockCooling4':  # models.py:628-632
         T, R = orc.temperature_radius(t, *p)
         return np.minimum(bb(bands, T, R, orc.z), bb(bands, 0.74 * T, 0.74 ** -2. * R, orc.z))

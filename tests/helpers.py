@@ -35,7 +35,7 @@ def small_problem(npts=60, seed=5):
 
 
 def oracle_log_posterior(pb):
-    model = ('ShockCooling', pb['orc'])
+    model = pb.get('model') or ('ShockCooling', pb['orc'])
 
     def fn(block):
         block = np.atleast_2d(block)

@@ -266,3 +266,39 @@ def test_c_oracle_matches_reference_numbers():
         assert relerr(got, s[f'scb/{tag}/ll']) < TOL
     got = O.c_shock_cooling_loglike(O.ShockCoolingOracle(0.01), s['scb/t'], bands, s['scb/y'], s['scb/dy'], s['sce/P'])
     assert relerr(got, s['sce/sc/ll']) < TOL  # zeros and NaNs where the reference has them
+
+
+def test_fitzpatrick99_known_answer_and_definition():
+    """The published law: the README example of the third-party `extinction` package (all printed digits), the
+    anchor value at 5470 A, the limits, and continuity where the ultraviolet formula takes over."""
+    got = O.fitzpatrick99(np.array([2000., 4000., 8000.]), 1.0, 3.1)
+    assert np.array_equal(np.round(got, 8), [2.76225609, 1.42325373, 0.55333671])
+    k5 = -5.13540e-02 + 1.00216 * 3.1 - 7.35778e-05 * 3.1 ** 2 - 3.1
+    assert O.fitzpatrick99(np.array([5470.]), 3.1, 3.1)[0] == pytest.approx(3.1 + k5, rel=1e-14)
+    assert abs(O.fitzpatrick99(np.array([1e9]), 1., 3.1)[0]) < 1e-4
+    lo, hi = O.fitzpatrick99(np.array([2700. * (1 + 1e-9), 2700. * (1 - 1e-9)]), 1., 3.1)
+    assert abs(lo - hi) < 1e-8
+    assert O.fitzpatrick99(np.array([4400.]), 3.1)[0] - O.fitzpatrick99(np.array([5500.]), 3.1)[0] == pytest.approx(1., abs=0.05)
+
+
+def test_shockcooling3_against_reference_vectors():
+    """'a': E(B-V) = 0, the reference's own arithmetic only; 'b': E(B-V) != 0, the reference's code around the
+    restated law (tools/refgen/standins/extinction)."""
+    g = golden('shockcooling3')
+    t, names, P = g['sc3/t'], [str(n) for n in g['sc3/names']], g['sc3/P']
+    bands = [O.band(n) for n in names]
+    model = ('ShockCooling3', O.ShockCoolingOracle(z=0.012))
+    P0 = P.copy()
+    P0[:, 5] = 0.
+    assert relerr(O.evaluate(model, t, bands, P0.T).T, g['sc3/a_y']) < TOL
+    assert relerr(O.evaluate(model, t, bands, P.T).T, g['sc3/b_y']) < TOL
+    assert relerr(np.array([O.evaluate(model, t, bands, p, reference_shaped=True) for p in P]), g['sc3/b_y']) < TOL
+    y, dy = g['sc3/flux'], g['sc3/dflux']
+    assert relerr(O.log_likelihood(model, t, bands, y, dy, P0.T), g['sc3/a_lnl']) < TOL
+    assert relerr(O.log_likelihood(model, t, bands, y, dy, P.T), g['sc3/b_lnl']) < TOL
+    assert relerr(O.log_likelihood(model, t, bands, y, dy, g['sc3/Ps'].T, use_sigma=True), g['sc3/b_lnl_sigma']) < TOL
+    # dense branch of the reference for parameter arrays: (every 15th filter row, ntimes, nwalkers)
+    rows = range(0, len(t), 15)
+    for j, r in enumerate(rows):
+        got = O.evaluate(model, t, [bands[r]] * len(t), P.T)
+        assert relerr(got, g['sc3/b_y_block'][j]) < TOL

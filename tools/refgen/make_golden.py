@@ -202,6 +202,49 @@ def gen_shockcooling(models, filters, Table, out):
     out['sce/sc2/ll'] = np.array([m2.log_likelihood(lc, p) for p in edge2])
 
 
+def gen_shockcooling3(models, filters, Table, out):
+    """ShockCooling3 (distance + reddening free, fits 'flux').  'sc3/a_*': E(B-V) = 0, the reference's own arithmetic
+    only (A_lambda = 0 whatever the law).  'sc3/b_*': E(B-V) != 0 -- the reference's code path (frames, R_V factor,
+    broadcasting: filters.py:14-33, 308-310) around the stand-in's restatement of the Fitzpatrick (1999) law, i.e.
+    these vectors pin the plumbing, not the law itself (see standins/extinction)."""
+    rng = np.random.default_rng(33)
+    npts = 90
+    names = rng.choice(['U', 'B', 'V', 'g', 'r', 'i', 'UVW2', 'z'], npts)
+    t = np.sort(rng.uniform(0.3, 10., npts))
+    f = [filters.filtdict[n] for n in names]
+    out['sc3/t'], out['sc3/names'] = t, np.array(names)
+    m = models.ShockCooling3(redshift=0.012)
+    truth = np.array([1.1, 0.6, 2.5, 1.8, 25., 0.15, 0.05])
+    n = 10
+    P = truth * (1. + 0.2 * rng.uniform(-1., 1., (n, 7)))
+    P[:, 6] = rng.uniform(-0.2, 0.25, n)
+    P[1, 4] = -P[1, 4]   # negative distance: dist ** 2 is positive
+    P[2, 0] = -0.5       # v_s < 0: power() zeroing
+    out['sc3/P'] = P
+    P0 = P.copy()
+    P0[:, 5] = 0.
+    out['sc3/a_y'] = np.array([m(t, f, *p) for p in P0])                   # (n, npts), per-walker scalar calls
+    out['sc3/b_y'] = np.array([m(t, f, *p) for p in P])
+    # parameter arrays make T two-dimensional, so the reference takes the dense branch (models.py:1161-1164):
+    # (nfilters, ntimes, nwalkers) even though len(t) == len(f); every 15th filter row is kept
+    block = m(t, f, *[P[:, j] for j in range(7)])
+    assert block.shape == (npts, npts, n)
+    out['sc3/b_y_block'] = block[::15]
+    yflux = m(t, f, *truth)
+    sgn = np.where(rng.uniform(size=npts) < 0.5, -1., 1.)
+    lc = make_lc(Table, filters, t, names, np.ones(npts), np.ones(npts))
+    lc['flux'] = yflux * (1. + 0.04 * sgn)
+    lc['dflux'] = 0.04 * yflux
+    out['sc3/flux'], out['sc3/dflux'] = np.asarray(lc['flux']), np.asarray(lc['dflux'])
+    out['sc3/a_lnl'] = np.array([m.log_likelihood(lc, p) for p in P0])
+    out['sc3/b_lnl'] = np.array([m.log_likelihood(lc, p) for p in P])
+    Ps = np.column_stack([P, rng.uniform(0.1, 2., n)])
+    out['sc3/Ps'] = Ps
+    out['sc3/b_lnl_sigma'] = np.array([m.log_likelihood(lc, p, use_sigma=True, sigma_type='relative') for p in Ps])
+    out['sc3/b_TR'] = np.array(m.temperature_radius(t, *truth[[0, 1, 2, 3, 6]]))
+    out['sc3/filter_ext'] = np.array([filters.filtdict[x].extinction(0.1, 3.1, z=0.) for x in 'UBVgri'])
+
+
 def gen_config2(models, filters, Table, out, nwalkers=48):
     """BASELINE.json configs[1] photometry and reference log-likelihoods for a walker block."""
     rng = np.random.default_rng(20241024)
@@ -442,6 +485,7 @@ def main():
         'primitives': lambda o: (gen_constants(models, filters, bolometric, o), gen_planck(models, filters, o),
                                  gen_priors_misc(models, filters, bolometric, lightcurve, o)),
         'shockcooling': lambda o: gen_shockcooling(models, filters, Table, o),
+        'shockcooling3': lambda o: gen_shockcooling3(models, filters, Table, o),
         'companion': lambda o: gen_companion(models, filters, Table, o),
         'config2': lambda o: gen_config2(models, filters, Table, o),
         'config3': lambda o: gen_config3(models, filters, Table, o),
