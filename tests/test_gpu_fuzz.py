@@ -66,6 +66,16 @@ def test_shock_cooling_family_fuzz(seed):
         want = O.log_likelihood(orc, t, bands, y, dy, sig.T, True, mode)
         assert relerr(model.log_likelihood(lc, sig, True, mode), want) < 2e-11
 
+    # ShockCooling3: distance and reddening free, fits 'flux' (full tables only)
+    m3, o3 = M.ShockCooling3(redshift=z, **kw), ('ShockCooling3', O.ShockCoolingOracle(z, **kw))
+    P = _params(rng, [0.1, 0.05, 0.2, 0.1, 1., 0., -5.], [5., 3., 10., 8., 100., 1.5, 10.], 12, 0.05)
+    lc3 = {'MJD': t, 'filter': names, 'flux': y * 1e-47, 'dflux': dy * 1e-47}
+    eng = m3.engine_for(lc3)
+    eng.set_variant(min(variant, 1))
+    assert relerr(eng.evaluate(P), O.evaluate(o3, t, bands, P.T).T) < 2e-11, ('ShockCooling3', z)
+    want = O.log_likelihood(o3, t, bands, lc3['flux'], lc3['dflux'], P.T)
+    assert relerr(m3.log_likelihood(lc3, P), want) < 2e-11, ('ShockCooling3', z)
+
 
 @pytest.mark.parametrize('seed', range(6))
 def test_companion_family_fuzz(seed):
