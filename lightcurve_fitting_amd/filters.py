@@ -90,7 +90,7 @@ COMPRESSION_TOL = 2e-14
 _T_GRID = np.geomspace(0.2, 2e4, 101)
 
 
-def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32)):
+def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32), max_tmin=2.0, min_ratio=2.):
     """Shorter table ``(a', W')`` with ``sum W'/(e^{a'/T} - 1) == sum W/(e^{a/T} - 1)`` to ``tol`` for every
     temperature ``T >= t_min``: the Gauss rule of the table's own discrete measure (1/(e^{a/T} - 1) is analytic in a,
     so a rule exact to polynomial degree 2m-1 converges geometrically in m; it degrades only when the band spans many
@@ -101,7 +101,7 @@ def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32)):
     with np.errstate(over='ignore'):
         full = np.array([np.sum(w / np.expm1(a / t)) for t in _T_GRID])
     for m in orders:
-        if 2 * m > len(a):
+        if min_ratio * m > len(a):
             break
         ag, wg = gauss_rule(a, w, m)
         if not (np.all(wg > 0.) and np.all(ag > 0.)):
@@ -111,7 +111,7 @@ def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32)):
         ok = np.abs(comp - full) <= tol * np.abs(full)
         bad = np.nonzero(~ok)[0]
         first_good = 0 if len(bad) == 0 else bad[-1] + 1
-        if first_good < len(_T_GRID) and _T_GRID[first_good] <= 2.0:
+        if first_good < len(_T_GRID) and _T_GRID[first_good] <= max_tmin:
             # one grid step of margin above the last failing temperature
             t_min = _T_GRID[min(first_good + 1, len(_T_GRID) - 1)] if len(bad) else 0.
             return np.ascontiguousarray(ag[::-1]), np.ascontiguousarray(wg[::-1]), float(t_min)
@@ -355,7 +355,10 @@ class PackedTables:
         ca, cw, coff, tmin = [], [], [0], []
         for i in range(len(self.filters)):
             a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
-            comp = compress_planck_table(a, w) if compress and len(a) >= 24 else None
+            if os.environ.get('LCF_EXPERIMENT_HOT') == '1':
+                comp = compress_planck_table(a, w, orders=(8,), max_tmin=6., min_ratio=1.1) if compress else None
+            else:
+                comp = compress_planck_table(a, w) if compress and len(a) >= 24 else None
             if comp is None:
                 tmin.append(np.inf)
             else:
