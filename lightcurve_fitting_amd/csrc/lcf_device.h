@@ -10,6 +10,7 @@
 namespace lcf {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kMaxParts = 8;     // workgroups per walker in the likelihood kernel, at most
 constexpr int kFewEpochs = 128;  // up to this many epochs one wave per proposal computes the thermal states
 constexpr int kTargetGroups = 4096;  // population mode: workgroups per likelihood launch worth splitting proposals for
 constexpr int kNCoef = 8;        // derived per-walker coefficients
@@ -49,11 +50,13 @@ struct DevProblem {
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
     int n_epochs, use_therm, use_ctab, n_tab;
-    int n_parts, cpb, pad2, pad3;  // workgroups per walker, point chunks per workgroup
+    int n_parts, cpb, pad2, pad3;  // workgroups per walker ("parts"), most point chunks in one part
+    int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs
+    int pad4[3];
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double sigma_unit_abs;  // median(dy)
-    // points, sorted by filter
+    // points, ordered by (part, filter)
     const double* t;
     const double* y;
     const double* dy;

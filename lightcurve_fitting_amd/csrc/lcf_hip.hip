@@ -155,17 +155,17 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
 
     double term = 0.;
+    const int p0 = pb.part_start[part], p1 = pb.part_start[part + 1];  // this part's points
     constexpr int kPre = 4;  // chunks whose operands are fetched together, before any band sum starts
-    for (int k0 = 0; k0 < pb.cpb; k0 += kPre) {
+    for (int k0 = 0; k0 * kBlock < p1 - p0; k0 += kPre) {
         int idx[kPre], filt[kPre];
         int4 desc[kPre];
         double itm[kPre], tin[kPre], yv[kPre], idy[kPre];
         double2 th[kPre];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
-            const int chunk = part + (k0 + u) * pb.n_parts;
-            const int i = chunk * kBlock + tid;
-            idx[u] = (k0 + u < pb.cpb && chunk < pb.n_chunks && i < pb.n_points) ? i : -1;
+            const int i = p0 + (k0 + u) * kBlock + tid;
+            idx[u] = i < p1 ? i : -1;
             if (idx[u] < 0) continue;
             desc[u] = pb.pt_desc[i];
             itm[u] = pb.pt_inv_tmin[i];
@@ -834,10 +834,42 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(LCF_ERR_HIP, "hipStreamCreate failed"));
 
-    // ---- sort points by filter (stable), build per-point table slices and per-chunk LDS windows ----
+    // ---- order the points: n_parts contiguous ranges of observation epochs ("parts", one workgroup per walker
+    // each), sorted by filter inside a part (waves then share a band table).  A part owning whole epochs means its
+    // workgroup needs the thermal states of those epochs only. ----
+    // distinct observation times (exact equality): the thermal state depends on (walker, time) only
+    const bool all_finite_t = std::all_of(pr->t, pr->t + N, [](double v) { return std::isfinite(v); });
+    std::vector<double> epochs(pr->t, pr->t + N);
+    std::sort(epochs.begin(), epochs.end());
+    epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
+    const int n_chunks_all = std::max(1, (N + kBlock - 1) / kBlock);
+    // workgroups per walker: enough to fill the chip at a few hundred walkers, few enough to amortise the prologue
+    int n_parts = std::min(n_chunks_all, 4);
+    if (const char* env = std::getenv("LCF_PARTS"))
+        n_parts = std::max(1, std::min(std::min(n_chunks_all, kMaxParts), std::atoi(env)));
     std::vector<int> order(N);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pr->filt_idx[a] < pr->filt_idx[b]; });
+    auto epoch_of = [&](int i) {
+        return all_finite_t ? (int)(std::lower_bound(epochs.begin(), epochs.end(), pr->t[i]) - epochs.begin()) : i;
+    };
+    std::vector<int> ep_of(N);
+    for (int i = 0; i < N; ++i) ep_of[i] = epoch_of(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ep_of[a] < ep_of[b]; });
+    std::vector<int> part_start(kMaxParts + 1, N);
+    part_start[0] = 0;
+    {
+        int made = 0;
+        for (int j = 1; j < n_parts; ++j) {  // boundary j: the first epoch change at or after the equal-count split
+            int b = (int)((long long)N * j / n_parts);
+            while (b < N && b > 0 && ep_of[order[b]] == ep_of[order[b - 1]]) ++b;
+            if (b > part_start[made] && b < N) part_start[++made] = b;
+        }
+        n_parts = made + 1;
+        for (int j = n_parts; j <= kMaxParts; ++j) part_start[j] = N;
+    }
+    for (int j = 0; j < n_parts; ++j)
+        std::stable_sort(order.begin() + part_start[j], order.begin() + part_start[j + 1],
+                         [&](int a, int b) { return pr->filt_idx[a] < pr->filt_idx[b]; });
     std::vector<double> ht(N), hy(N), hdy(N);
     std::vector<int> hoff(N), hcnt(N), hfilt(N), horig(N);
     double lognorm = 0.;
@@ -906,20 +938,15 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         std::sort(sorted_dy.begin(), sorted_dy.end());
         med = (N & 1) ? sorted_dy[N / 2] : 0.5 * (sorted_dy[N / 2 - 1] + sorted_dy[N / 2]);
     }
-    // distinct observation times (exact equality): the thermal state depends on (walker, time) only
-    std::vector<double> epochs(ht);
-    std::sort(epochs.begin(), epochs.end());
-    epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
     std::vector<int> hepoch(N);
     for (int i = 0; i < N; ++i)
         hepoch[i] = (int)(std::lower_bound(epochs.begin(), epochs.end(), ht[i]) - epochs.begin());
-    const bool all_finite_t = std::all_of(ht.begin(), ht.end(), [](double v) { return std::isfinite(v); });
-    const int n_chunks = std::max(1, (N + kBlock - 1) / kBlock);
-    // workgroups per walker: enough to fill the chip at a few hundred walkers, few enough to amortise the prologue
-    int n_parts = std::min(n_chunks, 4);
-    if (const char* env = std::getenv("LCF_PARTS")) n_parts = std::max(1, std::min(n_chunks, std::atoi(env)));
-    const int cpb = (n_chunks + n_parts - 1) / n_parts;
-    n_parts = (n_chunks + cpb - 1) / cpb;
+    int n_chunks = 0, cpb = 1;  // chunks of kBlock points: total over the parts, and the most in one part
+    for (int j = 0; j < n_parts; ++j) {
+        const int c = (part_start[j + 1] - part_start[j] + kBlock - 1) / kBlock;
+        n_chunks += c;
+        cpb = std::max(cpb, c);
+    }
     std::vector<int> htaboff(pfull);
     if (htab.empty()) htab.push_back(make_double2(1., 0.));
     std::vector<int4> hdesc(N);
@@ -938,6 +965,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_chunks = n_chunks;
     dp.n_parts = n_parts;
     dp.cpb = cpb;
+    for (int j = 0; j <= kMaxParts; ++j) dp.part_start[j] = part_start[j];
     dp.n_tab = (int)htab.size();
     dp.n_filters = NF;
     dp.n_dim = n_dim;
@@ -1625,9 +1653,12 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         const long long slots = (long long)n * s->ds.n_half;
         const int want = (int)std::max<long long>(1, (kTargetGroups + slots - 1) / slots);
         const int parts = std::min(ip.n_parts, want);
-        const int cpb = (ip.n_chunks + parts - 1) / parts;
-        ip.cpb = cpb;
-        ip.n_parts = (ip.n_chunks + cpb - 1) / cpb;
+        const int mg = (ip.n_parts + parts - 1) / parts;  // engine parts merged into one workgroup's share
+        const int np = (ip.n_parts + mg - 1) / mg;
+        const DevProblem& ep = s->e->dp;
+        for (int J = 0; J <= kMaxParts; ++J)
+            ip.part_start[J] = J < np ? ep.part_start[J * mg] : ep.n_points;
+        ip.n_parts = np;
         lds = std::max(lds, s->e->lds_bytes);
         max_epochs = std::max(max_epochs, s->e->dp.n_epochs);
         max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
