@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 3
+#define LCF_ABI_VERSION 4
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -104,6 +104,13 @@ typedef struct lcf_problem {
     const double* ctab_a;     /* [ctab_off[n_filters]] */
     const double* ctab_w;     /* [ctab_off[n_filters]] */
     const double* ctab_tmin;  /* [n_filters] kK; +inf = never use the compressed table of this filter */
+    /* Optional second compressed level (all NULL = none; needs the first): a still shorter table per filter, valid
+     * above a higher temperature htab_tmin[i] >= ctab_tmin[i].  Per data point the engine takes the shortest table
+     * that is valid at the point's temperature: hot, else cool, else full. */
+    const int32_t* htab_off;  /* [n_filters + 1] */
+    const double* htab_a;     /* [htab_off[n_filters]] */
+    const double* htab_w;     /* [htab_off[n_filters]] */
+    const double* htab_tmin;  /* [n_filters] kK */
     const int32_t* filt_kasen_par; /* [n_filters] or NULL */
     const int32_t* filt_sifto_par; /* [n_filters] or NULL */
     const int32_t* filt_dt_par;    /* [n_filters] or NULL */

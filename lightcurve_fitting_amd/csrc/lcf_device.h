@@ -15,7 +15,8 @@ constexpr int kFewEpochs = 128;  // up to this many epochs one wave per proposal
 constexpr int kTargetGroups = 4096;  // population mode: workgroups per likelihood launch worth splitting proposals for
 constexpr int kNCoef = 8;        // derived per-walker coefficients
 constexpr int kMaxDim = 16;      // max parameters per walker
-constexpr int kLdsTabMax = 3900; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
+constexpr int kLdsFiltMax = 64;   // filters whose descriptors are staged with the tables
+constexpr int kLdsTabMax = 3700; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
 
 constexpr double kKB = 0.08617333262145178;   // eV / kK                 models.py:10
 constexpr double kC3 = 5.38477047522316e-19;  //                          models.py:11
@@ -45,14 +46,23 @@ struct PriorDev {
 };
 
 // Immutable per-problem device data (passed to kernels by value).
+// Tables of one filter inside `tab` (offsets / counts in samples, counts padded to quads): the full table and up to
+// two Gauss-compressed companions, "cool" (valid for 1/T <= inv_tmin) and the shorter "hot" (1/T <= inv_tmin2).
+struct FiltDesc {
+    int off, cnt, coff, ccnt, hoff, hcnt, pad0, pad1;
+    double inv_tmin, inv_tmin2;  // 0 = that level does not exist
+};
+static_assert(sizeof(FiltDesc) == 48, "three double2 per filter in LDS");
+
 struct DevProblem {
     int model, n_points, n_chunks, n_filters;
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
     int n_epochs, use_therm, use_ctab, n_tab;
     int n_parts, cpb, pad2, pad3;  // workgroups per walker ("parts"), most point chunks in one part
-    int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs
-    int pad4[3];
+    int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs ...
+    int part_ep0[kMaxParts + 1];    // ... namely the epochs [part_ep0[j], part_ep0[j+1]) (when use_therm)
+    int pad4[2];
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double sigma_unit_abs;  // median(dy)
@@ -61,8 +71,7 @@ struct DevProblem {
     const double* y;
     const double* dy;
     const double* inv_dy;     // 1 / dy
-    const int4* pt_desc;      // tables of the point's filter: (full offset, full count, compressed offset, count)
-    const double* pt_inv_tmin;  // 1 / (lowest temperature at which the compressed table is valid); 0 = never
+    const FiltDesc* f_desc;   // [n_filters] where each filter's tables are, and from which temperature they hold
     const int* pt_filt;  // filter index
     const int* pt_orig;  // index in the caller's order
     const int* pt_epoch; // index into epoch_t (distinct observation times)
@@ -77,6 +86,15 @@ struct DevProblem {
     const double* spl;  // [n_filters][n_knots-1][4]
     const PriorDev* priors;
 };
+
+// a[j] for a small array that lives in the kernel arguments: a chain of scalar selects (indexing it dynamically
+// would make the compiler copy the array to scratch memory)
+__device__ inline int part_entry(const int (&a)[kMaxParts + 1], int j) {
+    int v = a[0];
+#pragma unroll
+    for (int k = 1; k <= kMaxParts; ++k) v = j == k ? a[k] : v;
+    return v;
+}
 
 // power() of the reference: base > 0 ? base**exp : 0, also for NaN bases.  models.py:42-48
 __device__ inline double pw(double base, double e) { return base > 0. ? pow(base, e) : 0.; }

@@ -1,13 +1,14 @@
 // MI355X (gfx950) batched light-curve log-likelihood engine: kernels + C ABI (include/lcf.h).
 //
 // Data layout in HBM (all float64 unless noted):
-//   photometry  t[N], y[N], dy[N], 1/dy[N], int32 pt_filt[N], pt_orig[N], pt_epoch[N], int4 pt_desc[N], 1/t_min[N]
-//               -- points stable-sorted by filter; distinct observation times epoch_t[n_epochs]
+//   photometry  t[N], y[N], dy[N], 1/dy[N], int32 pt_filt[N], pt_orig[N], pt_epoch[N]; per filter a FiltDesc
+//               -- points ordered by (part, filter), a part being a contiguous range of observation epochs;
+//               distinct observation times epoch_t[n_epochs]
 //   band tables tab[] = per filter [full | Gauss-compressed] interleaved (a_k, W_k) pairs, each padded to quads
 //   walkers     P[n][n_dim] row-major; derived coefficients coef[n][8]; thermal states therm[n][n_epochs] (1/T, R^2);
 //               partial chi^2 sums part[n][n_parts]
-// Work decomposition (k_points): workgroup = (walker w, part j) walks the point chunks j, j + n_parts, ... of 256
-// filter-sorted points; lane = one data point.  The exp table and all band tables are staged in LDS once per
+// Work decomposition (k_points / k_fused): workgroup = (walker w, part j) walks the points of part j in chunks of
+// 256; lane = one data point.  The exp table and all band tables are staged in LDS once per
 // workgroup; lanes of a wave read the same LDS address (broadcast) because neighbouring points share a filter.
 // Reductions are wave shuffles + a fixed-order LDS sum: no float atomics anywhere, results are bitwise reproducible
 // run to run and independent of the GPU count.  The sampler (k_step, k_draws, k_make_perm), the multi-transient
@@ -27,6 +28,13 @@
 #include "lcf.h"
 #include "lcf_device.h"
 #include "lcf_host.h"
+
+#ifndef LCF_KPRE
+#define LCF_KPRE 4
+#endif
+#ifndef LCF_WAVES
+#define LCF_WAVES 4
+#endif
 
 using namespace lcf;
 
@@ -53,26 +61,33 @@ __global__ void k_prepare(const DevProblem pb, int n, const double* __restrict__
     lprior[w] = with_prior ? walker_log_prior(pb, p) : 0.;
 }
 
-// The two tables of a point's filter (offsets relative to `base`): the full one and its Gauss-compressed companion,
-// valid for 1/T <= inv_tmin.
+// The tables of a point's filter (offsets relative to `base`): the full one and up to two Gauss-compressed
+// companions -- the "cool" one valid for 1/T <= inv_tmin, and a shorter "hot" one valid for 1/T <= inv_tmin2
+// (inv_tmin2 <= inv_tmin; 0 = none).  The shortest valid table is used.
 template <class TabPtr>
 struct TabSel {
     TabPtr base;
-    int off, cnt, coff, ccnt;
-    double inv_tmin;
+    long long full, cool, hot;  // offset | count << 32 of each table (count 0: the level does not exist)
+    double inv_tmin, inv_tmin2;
 };
 
+__device__ __forceinline__ long long tab_slice(int off, int cnt) {
+    return (long long)(unsigned int)off | ((long long)cnt << 32);
+}
+
 template <int VARIANT, class TabPtr>
-__device__ inline double band_sum_at(const TabSel<TabPtr>& ts, bool use_ctab, double invT, const ExpTab et) {
-    const bool c = use_ctab && invT <= ts.inv_tmin;
-    const TabPtr tab = ts.base + (c ? ts.coff : ts.off);
-    const int cnt = c ? ts.ccnt : ts.cnt;
+__device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use_ctab, double invT, const ExpTab et) {
+    long long sel = ts.full;
+    sel = (use_ctab && invT <= ts.inv_tmin) ? ts.cool : sel;
+    sel = (use_ctab && invT <= ts.inv_tmin2) ? ts.hot : sel;
+    const TabPtr tab = ts.base + (int)sel;
+    const int cnt = (int)(sel >> 32);
     return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
 }
 
 // Everything one lane does for its data point after the thermal state (1/T, R_bb^2): band sum(s) -> template term.
 template <int VARIANT, class TabPtr>
-__device__ inline double point_model(const DevProblem& pb, const double* __restrict__ c,
+__device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
                                      const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
                                      const ExpTab et, double invT, double pref) {
     double S = 0.;
@@ -114,64 +129,54 @@ __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_l
     therm[(size_t)w * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
 }
 
-// MODE 0: chi^2 partial sums -> part[w][n_parts];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
-// Workgroup = (walker w, part j): it walks the point chunks j, j + n_parts, j + 2 n_parts, ... (a strided share, so
-// that every workgroup sees a similar mix of filters) with the exp table and ALL band tables staged in LDS once, and
-// reduces once at the end.
-template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
-__device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int n_w, const double* __restrict__ P,
-                                   const double* __restrict__ coef, const double* __restrict__ lprior,
-                                   const double2* __restrict__ therm, double* __restrict__ out0,
-                                   double* __restrict__ out1) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
-    double* red = exptab + kExpTabSize;                                   // 4 doubles
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
-
-    const int part = bid / n_w;
-    const int w = w_lo + bid % n_w;
-    const int tid = threadIdx.x;
-
-    if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
-
-    if (VARIANT == 1 && tid < kExpTabSize) exptab[tid] = pb.exp2tab[tid];
+// Stage the exp table and ALL band tables in LDS; thread t of nt.  ShockCooling3: the walker's reddening goes into
+// the staged weights.
+template <int VARIANT, bool LDS_TAB>
+__device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ exptab, double2* __restrict__ ltab,
+                                    double ebv, int t, int nt) {
+    if (VARIANT == 1)
+        for (int k = t; k < kExpTabSize; k += nt) exptab[k] = pb.exp2tab[k];
     if (LDS_TAB) {
-        if (pb.model == kShockCooling3) {  // this walker's reddening goes into the staged weights
-            const double ebv = coef[(size_t)w * kNCoef + 6];
-            for (int k = tid; k < pb.n_tab; k += kBlock) {
+        // filter descriptors (48 B = 3 double2 each) behind the tables
+        double2* lfd = ltab + pb.n_tab;
+        const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
+        for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
+        if (pb.model == kShockCooling3) {
+            for (int k = t; k < pb.n_tab; k += nt) {
                 double2 aw = pb.tab[k];
                 aw.y *= exp2(-ebv * pb.tab_ext[k]);
                 ltab[k] = aw;
             }
         } else {
-            for (int k = tid; k < pb.n_tab; k += kBlock) ltab[k] = pb.tab[k];
+            for (int k = t; k < pb.n_tab; k += nt) ltab[k] = pb.tab[k];
         }
     }
-    __syncthreads();
+}
 
-    const double* c = coef + (size_t)w * kNCoef;   // wave-uniform -> scalar loads
-    const double* p = P + (size_t)w * pb.n_dim;
-    const ExpTab et{exptab};
-    const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
-
+// The points of part `part` for one walker: parameters p, coefficients c (global or LDS), thermal states
+// th[pt_epoch - e_off] when THERM.  MODE 0: returns this thread's share of chi^2;  MODE 1: y_fit -> out0[row][orig];
+// MODE 2: T, R_bb -> out0, out1.
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
+__device__ inline double points_loop(const DevProblem& pb, int part, size_t row, const double* __restrict__ p,
+                                     const double* __restrict__ c, const double2* __restrict__ th_base, int e_off,
+                                     const double2* tbase, const FiltDesc* fdesc, const ExpTab et,
+                                     double* __restrict__ out0, double* __restrict__ out1) {
+    const int tid = threadIdx.x;
     double term = 0.;
-    const int p0 = pb.part_start[part], p1 = pb.part_start[part + 1];  // this part's points
-    constexpr int kPre = 4;  // chunks whose operands are fetched together, before any band sum starts
+    const int p0 = part_entry(pb.part_start, part), p1 = part_entry(pb.part_start, part + 1);  // this part's points
+    constexpr int kPre = LCF_KPRE;  // chunks whose operands are fetched together, before any band sum starts
     for (int k0 = 0; k0 * kBlock < p1 - p0; k0 += kPre) {
         int idx[kPre], filt[kPre];
-        int4 desc[kPre];
-        double itm[kPre], tin[kPre], yv[kPre], idy[kPre];
+        double tin[kPre], yv[kPre], idy[kPre];
         double2 th[kPre];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int i = p0 + (k0 + u) * kBlock + tid;
             idx[u] = i < p1 ? i : -1;
             if (idx[u] < 0) continue;
-            desc[u] = pb.pt_desc[i];
-            itm[u] = pb.pt_inv_tmin[i];
             filt[u] = pb.pt_filt[i];
             tin[u] = pb.t[i];
-            if (THERM && MODE != 2) th[u] = therm[(size_t)w * pb.n_epochs + pb.pt_epoch[i]];
+            if (THERM && MODE != 2) th[u] = th_base[pb.pt_epoch[i] - e_off];
             if (MODE == 0) {
                 yv[u] = pb.y[i];
                 idy[u] = pb.use_sigma ? pb.dy[i] : pb.inv_dy[i];
@@ -181,7 +186,11 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
         for (int u = 0; u < kPre; ++u) {
             const int i = idx[u];
             if (i < 0) continue;
-            const TabSel<const double2*> ts{tbase, desc[u].x, desc[u].y, desc[u].z, desc[u].w, itm[u]};
+            // the filter's descriptor as three 16-byte reads (LDS when the tables are staged)
+            const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt[u];
+            const double2 d0 = fd[0], d1 = fd[1], d2 = fd[2];
+            const TabSel<const double2*> ts{tbase, __double_as_longlong(d0.x), __double_as_longlong(d0.y),
+                                            __double_as_longlong(d1.x), d2.x, d2.y};
             double invT, pref, Tk = 0.;
             if (THERM && MODE != 2) {
                 invT = th[u].x;
@@ -192,7 +201,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
             }
             if (MODE == 2) {
                 // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
-                const size_t j = (size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i];
+                const size_t j = row * pb.n_points + pb.pt_orig[i];
                 out0[j] = Tk;
                 out1[j] = sqrt(pref);
                 continue;
@@ -210,20 +219,54 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
                     term = fma(q, q, term);
                 }
             } else {
-                out0[(size_t)(w - w_lo) * pb.n_points + pb.pt_orig[i]] = yfit;
+                out0[row * pb.n_points + pb.pt_orig[i]] = yfit;
             }
         }
     }
-    if (MODE == 0) {
-        const double ws = wave_sum(term);
-        if ((tid & 63) == 0) red[tid >> 6] = ws;
-        __syncthreads();
-        if (tid == 0) out0[(size_t)w * pb.n_parts + part] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
+    return term;
+}
+
+// Workgroup reduction of the chi^2 shares in a fixed order; thread 0 stores the part's partial sum.
+__device__ inline void store_part_sum(double term, double* __restrict__ red, double* __restrict__ dst) {
+    const int tid = threadIdx.x;
+    const double ws = wave_sum(term);
+    if ((tid & 63) == 0) red[tid >> 6] = ws;
+    __syncthreads();
+    if (tid == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// MODE 0: chi^2 partial sums -> part[w][n_parts];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
+// Workgroup = (walker w, part j): it walks the points of part j (a range of epochs, sorted by filter) in chunks of
+// 256 with the exp table and ALL band tables staged in LDS once, and reduces once at the end.
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
+__device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int n_w, const double* __restrict__ P,
+                                   const double* __restrict__ coef, const double* __restrict__ lprior,
+                                   const double2* __restrict__ therm, double* __restrict__ out0,
+                                   double* __restrict__ out1) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
+    double* red = exptab + kExpTabSize;                                   // 4 doubles
+    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
+
+    const int part = bid / n_w;
+    const int w = w_lo + bid % n_w;
+
+    if (MODE == 0 && lprior[w] == -INFINITY) return;  // prior excludes the walker: likelihood skipped (fitting.py:125)
+
+    const double* c = coef + (size_t)w * kNCoef;   // wave-uniform -> scalar loads
+    stage_tables<VARIANT, LDS_TAB>(pb, exptab, ltab, pb.model == kShockCooling3 ? c[6] : 0., threadIdx.x, kBlock);
+    __syncthreads();
+
+    const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
+    const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_tab) : pb.f_desc;
+    const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
+        pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
+        tbase, fdesc, ExpTab{exptab}, out0, out1);
+    if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * pb.n_parts + part);
 }
 
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
-__global__ __launch_bounds__(kBlock) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
+__global__ __launch_bounds__(kBlock, LCF_WAVES) void k_points(const DevProblem pb, int w_lo, int n_w, const double* __restrict__ P,
                                                    const double* __restrict__ coef,
                                                    const double* __restrict__ lprior,
                                                    const double2* __restrict__ therm, double* __restrict__ out0,
@@ -266,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
     double S = 0.;
     if (Tk > 0. && Tk < kTmax) {
         const ExpTab et{exptab};
-        const TabSel<const double2*> ts{pb.tab, tab_off[2 * f], tab_off[2 * f + 1], ctab_off[2 * f],
-                                        ctab_off[2 * f + 1], 1. / ctmin[f]};
+        const TabSel<const double2*> ts{pb.tab, tab_slice(tab_off[2 * f], tab_off[2 * f + 1]),
+                                        tab_slice(ctab_off[2 * f], ctab_off[2 * f + 1]), 0, 1. / ctmin[f], 0.};
         S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 1. / Tk, et);
     }
     out[i] = r * r * S;
@@ -307,7 +350,7 @@ struct DevSampler {
     double* Q[2];       // [n_half][n_dim]     proposals
     SlotRec* rec[2];    // [n_half]
     double* newlp[2];   // [n_half]            log-posterior of the proposal (finalize kernel / all-gather)
-    const double* part; // [n_half][n_parts]   chi^2 partial sums of the latest evaluation
+    double* part2[2];   // [n_half][n_parts]   chi^2 partial sums of the evaluation of half-step parity 0 / 1
     double* chain;      // [n_steps][n_walkers][n_dim]
     double* chain_lp;   // [n_steps][n_walkers]
     long long* nacc;    // [n_walkers]
@@ -408,6 +451,145 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     draws[idx] = d;
 }
 
+// The serial part of a half-step for slot i, executed by ONE wave (lane = 0..63): accept tests of the previous
+// half-step (recomputed from the per-slot records, no hand-off between workgroups), the new proposal, and -- for a
+// slot this rank evaluates (`mine`) -- its coefficients and log-prior, left in sc[0..kNCoef] (LDS, lane 0 writes).
+// `primary`: this wave is the one that commits slot i of the previous half-step and publishes the proposal record
+// (exactly one wave per slot and launch is primary; the others only need the proposal for themselves).
+template <int ND>
+__device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, int i, bool primary, int lane,
+                                   int have_prev, long long prev_row, int have_next,
+                                   const DrawRec* __restrict__ draws, const DrawRec* __restrict__ prev_draws,
+                                   long long g, bool mine, double* __restrict__ sc, double* __restrict__ sq,
+                                   double* __restrict__ coef, double* __restrict__ lprior) {
+    const int prev_wid = (have_prev && primary) ? prev_draws[i].wid : 0;
+    PriorDev my_prior{0, 0, 0., 0., 0., 1.};
+    if (lane < pb.n_dim && pb.has_priors && have_next) my_prior = pb.priors[lane];
+    const int pp = (int)((g - 1) & 1), cp = (int)(g & 1);
+    constexpr int kD = ND > 0 ? ND : kMaxDim;     // array extent
+    const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
+    DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
+    if (have_next) dr = draws[i];
+    // --- roles: which accept test (if any) this lane evaluates ---
+    int rw = -1, rslot = -1;
+    if (lane == 0 && have_prev && primary) {
+        rslot = i;
+        rw = prev_wid;  // walker of slot i in the previous half-step (from its draw record)
+    } else if ((lane == 1 || lane == 2) && have_next) {
+        rw = lane == 1 ? dr.wid : dr.pid;
+        rslot = have_prev ? (lane == 1 ? dr.wprev : dr.pprev) : -1;
+    }
+    double row[kD], qrow[kD], lp_cur = 0., nlp = 0.;
+    bool ok = false;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) row[d] = qrow[d] = 0.;
+    if (rw >= 0) {
+        // everything the accept test and both outcomes need, in one wave of loads
+        const double* xs = sm.X + (size_t)rw * nd;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) row[d] = xs[d];
+        lp_cur = sm.LP[rw];
+        if (rslot >= 0) {
+            const SlotRec rc = sm.rec[pp][rslot];
+            const double* qs = sm.Q[pp] + (size_t)rslot * nd;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) qrow[d] = qs[d];
+            if (sm.inline_finalize) {
+                double sum = pb.use_sigma ? 0. : pb.log_norm_const;
+                for (int k = 0; k < pb.n_parts; ++k) sum += sm.part2[pp][(size_t)rslot * pb.n_parts + k];
+                nlp = rc.lpri == -INFINITY ? -INFINITY : rc.lpri - 0.5 * sum;
+            } else {
+                nlp = sm.newlp[pp][rslot];
+            }
+            ok = (rc.zl + nlp - rc.lp_old) > rc.lnu;  // emcee: (ndim-1) ln z + lp_new - lp_old > ln u
+            lp_cur = ok ? nlp : rc.lp_old;
+            if (ok) {
+#pragma unroll
+                for (int d = 0; d < kD; ++d) row[d] = qrow[d];
+            }
+        }
+    }
+    if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
+        if (nlp != nlp) atomicExch(sm.err, 1);
+        if (ok) {
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) sm.X[(size_t)rw * nd + d] = row[d];
+            sm.LP[rw] = nlp;
+            atomicAdd((unsigned long long*)&sm.nacc[rw], 1ull);
+        }
+        if (sm.store_chain) {
+            double* crow = sm.chain + ((size_t)prev_row * sm.n_walkers + rw) * nd;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) crow[d] = row[d];
+            sm.chain_lp[(size_t)prev_row * sm.n_walkers + rw] = lp_cur;
+        }
+    }
+    if (have_next) {
+        double q[kMaxDim], lq[kMaxDim];
+        double arg = 1.;
+#pragma unroll
+        for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
+#pragma unroll
+        for (int d = 0; d < kD; ++d) {
+            const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
+            q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
+            if (lane == d && d < pb.n_par) arg = q[d];
+        }
+        const double lp_i = __shfl(lp_cur, 1, 64);
+        if (!mine) {
+            // another rank evaluates this proposal: only what later accept tests need is published here
+            // (its log-prior reaches this rank inside the gathered log-posterior)
+            if (lane == 0 && primary) {
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
+                sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, 0.};
+            }
+            return;
+        }
+        const double lg = log(arg);  // one logarithm per lane, all at once
+#pragma unroll
+        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
+        double c[kNCoef];
+        walker_coefficients(pb, q, lq, c);
+        // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
+        double lpr = 0.;
+        if (pb.has_priors) {
+            double qv = 0.;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (lane == d) qv = q[d];
+            const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) lpr += __shfl(mine, d, 64);
+        }
+        if (lane == 0) {
+            for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
+            sc[kNCoef] = lpr;
+            if (sq) {  // the proposal itself, for a workgroup that goes on to evaluate it
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) sq[d] = q[d];
+            }
+            if (primary) {  // publish the per-slot records
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
+                sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
+                if (coef) {
+                    for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
+                    lprior[i] = lpr;
+                }
+            }
+        }
+    }
+}
+
 // One workgroup per (proposal slot i, epoch chunk): wave 0 commits half-step g - 1 for slot i (chunk 0 only) and draws
 // slot i of half-step g COOPERATIVELY -- the latency chain of a single thread (three accept tests with dependent
 // loads, then the logarithms of the proposal) is spread over lanes that run the same code on different data:
@@ -448,127 +630,9 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     const bool in_shard = do_thermal && mine;
     const int ep = ec * kBlock + lane;
     const double t_ep = (in_shard && ep < pb.n_epochs) ? pb.epoch_t[ep] : 0.;  // issued before the serial section
-    const int prev_wid = (have_prev && ec == 0) ? prev_draws[i].wid : 0;
-    PriorDev my_prior{0, 0, 0., 0., 0., 1.};
-    if (lane < pb.n_dim && pb.has_priors && have_next) my_prior = pb.priors[lane];
-    if (lane < 64) {
-        const int pp = (int)((g - 1) & 1), cp = (int)(g & 1);
-        constexpr int kD = ND > 0 ? ND : kMaxDim;     // array extent
-        const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
-        DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
-        if (have_next) dr = draws[i];
-        // --- roles: which accept test (if any) this lane evaluates ---
-        int rw = -1, rslot = -1;
-        if (lane == 0 && have_prev && ec == 0) {
-            rslot = i;
-            rw = prev_wid;  // walker of slot i in the previous half-step (from its draw record)
-        } else if ((lane == 1 || lane == 2) && have_next) {
-            rw = lane == 1 ? dr.wid : dr.pid;
-            rslot = have_prev ? (lane == 1 ? dr.wprev : dr.pprev) : -1;
-        }
-        double row[kD], qrow[kD], lp_cur = 0., nlp = 0.;
-        bool ok = false;
-#pragma unroll
-        for (int d = 0; d < kD; ++d) row[d] = qrow[d] = 0.;
-        if (rw >= 0) {
-            // everything the accept test and both outcomes need, in one wave of loads
-            const double* xs = sm.X + (size_t)rw * nd;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (d < nd) row[d] = xs[d];
-            lp_cur = sm.LP[rw];
-            if (rslot >= 0) {
-                const SlotRec rc = sm.rec[pp][rslot];
-                const double* qs = sm.Q[pp] + (size_t)rslot * nd;
-#pragma unroll
-                for (int d = 0; d < kD; ++d)
-                    if (d < nd) qrow[d] = qs[d];
-                if (sm.inline_finalize) {
-                    double sum = pb.use_sigma ? 0. : pb.log_norm_const;
-                    for (int k = 0; k < pb.n_parts; ++k) sum += sm.part[(size_t)rslot * pb.n_parts + k];
-                    nlp = rc.lpri == -INFINITY ? -INFINITY : rc.lpri - 0.5 * sum;
-                } else {
-                    nlp = sm.newlp[pp][rslot];
-                }
-                ok = (rc.zl + nlp - rc.lp_old) > rc.lnu;  // emcee: (ndim-1) ln z + lp_new - lp_old > ln u
-                lp_cur = ok ? nlp : rc.lp_old;
-                if (ok) {
-#pragma unroll
-                    for (int d = 0; d < kD; ++d) row[d] = qrow[d];
-                }
-            }
-        }
-        if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
-            if (nlp != nlp) atomicExch(sm.err, 1);
-            if (ok) {
-#pragma unroll
-                for (int d = 0; d < kD; ++d)
-                    if (d < nd) sm.X[(size_t)rw * nd + d] = row[d];
-                sm.LP[rw] = nlp;
-                atomicAdd((unsigned long long*)&sm.nacc[rw], 1ull);
-            }
-            if (sm.store_chain) {
-                double* crow = sm.chain + ((size_t)prev_row * sm.n_walkers + rw) * nd;
-#pragma unroll
-                for (int d = 0; d < kD; ++d)
-                    if (d < nd) crow[d] = row[d];
-                sm.chain_lp[(size_t)prev_row * sm.n_walkers + rw] = lp_cur;
-            }
-        }
-        if (have_next) {
-            double q[kMaxDim], lq[kMaxDim];
-            double arg = 1.;
-#pragma unroll
-            for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
-#pragma unroll
-            for (int d = 0; d < kD; ++d) {
-                const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
-                q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
-                if (lane == d && d < pb.n_par) arg = q[d];
-            }
-            const double lp_i = __shfl(lp_cur, 1, 64);
-            if (!mine) {
-                // another rank evaluates this proposal: only what later accept tests need is published here
-                // (its log-prior reaches this rank inside the gathered log-posterior)
-                if (lane == 0 && ec == 0) {
-#pragma unroll
-                    for (int d = 0; d < kD; ++d)
-                        if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
-                    sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, 0.};
-                }
-                return;
-            }
-            const double lg = log(arg);  // one logarithm per lane, all at once
-#pragma unroll
-            for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
-            double c[kNCoef];
-            walker_coefficients(pb, q, lq, c);
-            // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
-            double lpr = 0.;
-            if (pb.has_priors) {
-                double qv = 0.;
-#pragma unroll
-                for (int d = 0; d < kD; ++d)
-                    if (lane == d) qv = q[d];
-                const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
-#pragma unroll
-                for (int d = 0; d < kD; ++d)
-                    if (d < nd) lpr += __shfl(mine, d, 64);
-            }
-            if (lane == 0) {
-                for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
-                sc[kNCoef] = lpr;
-                if (ec == 0) {  // publish the per-slot records
-#pragma unroll
-                    for (int d = 0; d < kD; ++d)
-                        if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
-                    sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
-                    for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
-                    lprior[i] = lpr;
-                }
-            }
-        }
-    }
+    if (lane < 64)
+        step_serial<ND>(pb, sm, i, ec == 0, lane, have_prev, prev_row, have_next, draws, prev_draws, g, mine, sc, nullptr,
+                        coef, lprior);
     if (!have_next || !in_shard) return;
     __syncthreads();
     if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
@@ -592,6 +656,67 @@ __global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevS
               coef, lprior, therm);
 }
 
+// ---- single-GPU fit: the whole half-step in ONE launch ---------------------------------------------------------------
+// Workgroup = (proposal slot i, part j).  Wave 0 runs the serial part (every part's workgroup redundantly: a few
+// hundred cycles, and no workgroup then waits for another; part 0 is the one that commits and publishes) while waves
+// 1-3 stage the tables; then all threads compute the thermal states of the part's own epochs straight into LDS and walk
+// the part's points.  Against k_step + k_points this saves a launch, the round trip of the thermal states and the
+// coefficients through memory, and the second staging.  The partial sums are double-buffered by half-step parity: this
+// launch reads the previous half-step's for its accept tests and writes its own.  Same arithmetic in the same order
+// as the two-kernel path: chains are bitwise identical.
+constexpr int kFusedScratch = kNCoef + 2 + kMaxDim + (kMaxDim & 1);  // doubles: coefficients + log-prior, proposal
+
+// A value every lane holds identically (read from LDS), moved to scalar registers: the per-walker coefficients are
+// used by every band sum, and as vector registers they would cost the kernel its occupancy.
+__device__ inline double uniform_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int ND, int VARIANT, bool THERM>
+__global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb, const DevSampler sm, int have_prev,
+                                                  long long prev_row, const DrawRec* __restrict__ draws,
+                                                  const DrawRec* __restrict__ prev_draws, long long g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* exptab = reinterpret_cast<double*>(smem);
+    double* red = exptab + kExpTabSize;
+    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
+    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_tab);
+    double* sc = reinterpret_cast<double*>(ltab + pb.n_tab + 3 * pb.n_filters);
+    double* sq = sc + kNCoef + 2;
+    double2* lth = reinterpret_cast<double2*>(sc + kFusedScratch);
+    const int nh = sm.n_half;
+    const int part = blockIdx.x / nh, i = blockIdx.x % nh;
+    const int tid = threadIdx.x;
+    const bool reddened = pb.model == kShockCooling3;
+    if (tid < 64)
+        step_serial<ND>(pb, sm, i, part == 0, tid, have_prev, prev_row, 1, draws, prev_draws, g, true, sc, sq, nullptr,
+                        nullptr);
+    else if (!reddened)
+        stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kBlock - 64);
+    __syncthreads();
+    if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
+    double cs[kNCoef];
+#pragma unroll
+    for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
+    if (reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, cs[6], tid, kBlock);
+    const int e0 = THERM ? part_entry(pb.part_ep0, part) : 0;
+    if (THERM) {
+        const int e1 = part_entry(pb.part_ep0, part + 1);
+        for (int e = e0 + tid; e < e1; e += kBlock) {
+            double T, pref;
+            thermal_state(pb, cs, pb.epoch_t[e], T, pref);
+            lth[e - e0] = make_double2(T > 0. ? 1. / T : 0., pref);
+        }
+    }
+    if (THERM || reddened) __syncthreads();
+    const double term = points_loop<VARIANT, 0, true, THERM>(pb, part, 0, sq, cs, lth, e0, ltab, fdesc, ExpTab{exptab},
+                                                             nullptr, nullptr);
+    store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * pb.n_parts + part);
+}
+
 // ---- population mode: one launch covers the same half-step of MANY independent transients (blockIdx.y) --------------
 struct MultiItem {
     DevProblem pb;
@@ -600,7 +725,6 @@ struct MultiItem {
     double* coef;
     double* lprior;
     double2* therm;
-    double* part;
 };
 
 template <int ND>
@@ -622,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void k_points_multi(const MultiItem* __rest
     const int nh = it.sm.n_half;
     if ((int)blockIdx.x >= nh * it.pb.n_parts) return;
     points_body<VARIANT, 0, LDS_TAB, THERM>(it.pb, blockIdx.x, 0, nh, it.sm.Q[parity], it.coef, it.lprior, it.therm,
-                                            it.part, nullptr);
+                                            it.sm.part2[parity], nullptr);
 }
 
 }  // namespace
@@ -653,6 +777,7 @@ struct lcf_engine {
     int* d_ctab_off = nullptr;  // per filter: (offset, count) of the compressed table
     double* d_ctmin = nullptr;
     bool have_ctab = false;
+    int max_part_epochs = 0;  // most distinct epochs in one part (LDS need of the fused sampler kernel)
     // workspace for n walkers
     int64_t cap = 0;
     double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
@@ -843,8 +968,10 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::sort(epochs.begin(), epochs.end());
     epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
     const int n_chunks_all = std::max(1, (N + kBlock - 1) / kBlock);
-    // workgroups per walker: enough to fill the chip at a few hundred walkers, few enough to amortise the prologue
-    int n_parts = std::min(n_chunks_all, 4);
+    // workgroups per walker: every one repeats the prologue (table staging; in the fused sampler kernel also the
+    // serial part of the half-step), so few of them -- two up to 16 chunks, then one per 8 chunks (measured on the
+    // 1024-walker, 3000-point fit: 2 parts 52 us/step, 4 parts 61, 8 parts 83)
+    int n_parts = std::min(n_chunks_all, std::min(kMaxParts, std::max(2, (n_chunks_all + 7) / 8)));
     if (const char* env = std::getenv("LCF_PARTS"))
         n_parts = std::max(1, std::min(std::min(n_chunks_all, kMaxParts), std::atoi(env)));
     std::vector<int> order(N);
@@ -871,21 +998,28 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         std::stable_sort(order.begin() + part_start[j], order.begin() + part_start[j + 1],
                          [&](int a, int b) { return pr->filt_idx[a] < pr->filt_idx[b]; });
     std::vector<double> ht(N), hy(N), hdy(N);
-    std::vector<int> hoff(N), hcnt(N), hfilt(N), horig(N);
+    std::vector<int> hfilt(N), horig(N);
     double lognorm = 0.;
     int64_t samples = 0;
     // device table: per filter [full | compressed], each padded to a multiple of four samples with zero weights
     // (exactly 0 contribution)
     // (a reddened model reweights the samples per walker: the compressed tables do not apply)
     const bool have_ctab = pr->ctab_off && pr->ctab_a && pr->ctab_w && pr->ctab_tmin && !reddened;
+    const bool have_htab = have_ctab && pr->htab_off && pr->htab_a && pr->htab_w && pr->htab_tmin;
+    if (have_htab) {
+        if (pr->htab_off[0] != 0) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "htab_off[0] must be 0"));
+        for (int f = 0; f < NF; ++f)
+            if (pr->htab_off[f + 1] < pr->htab_off[f] || pr->htab_off[f + 1] - pr->htab_off[f] > 252)
+                return bail(fail(LCF_ERR_INVALID_ARGUMENT, "htab_off must be non-decreasing, <= 252 samples a filter"));
+    }
     if (have_ctab) {
         if (pr->ctab_off[0] != 0) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off[0] must be 0"));
         for (int f = 0; f < NF; ++f)
             if (pr->ctab_off[f + 1] < pr->ctab_off[f])
                 return bail(fail(LCF_ERR_INVALID_ARGUMENT, "ctab_off must be non-decreasing"));
     }
-    std::vector<int> pfull(2 * NF, 0), pcomp(2 * NF, 0);  // (offset, count) pairs
-    std::vector<double> ptmin(NF, INFINITY);
+    std::vector<int> pfull(2 * NF, 0), pcomp(2 * NF, 0), phot(2 * NF, 0);  // (offset, count) pairs
+    std::vector<double> ptmin(NF, INFINITY), ptmin2(NF, INFINITY);
     std::vector<double2> htab;
     std::vector<double> hext;  // reddened models: 0.4 log2(10) A_k / E(B-V), aligned with htab
     auto append = [&](const double* a, const double* w, int k0, int k1, int* slot) -> bool {
@@ -913,10 +1047,16 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
             ptmin[f] = pr->ctab_tmin[f];
             if (!(ptmin[f] >= 0.)) ok = false;
         }
-        if (!ok) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0, finite W_k, t_min >= 0"));
+        if (ok && have_htab && pr->htab_off[f + 1] > pr->htab_off[f]) {
+            ok = append(pr->htab_a, pr->htab_w, pr->htab_off[f], pr->htab_off[f + 1], &phot[2 * f]);
+            ptmin2[f] = pr->htab_tmin[f];
+            // the hot level must not claim a wider range than the cool one (selection tests it first)
+            if (!(ptmin2[f] >= 0.) || (pcomp[2 * f + 1] > 0 && ptmin2[f] < ptmin[f])) ok = false;
+        }
+        if (!ok)
+            return bail(fail(LCF_ERR_INVALID_ARGUMENT,
+                             "band tables need finite a_k > 0, finite W_k, t_min >= 0 (hot level: t_min >= the cool one's)"));
     }
-    std::vector<int> hcoff(N), hccnt(N);
-    std::vector<double> htmin(N);
     for (int i = 0; i < N; ++i) {
         const int o = order[i], f = pr->filt_idx[o];
         ht[i] = pr->t[o];
@@ -924,11 +1064,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         hdy[i] = pr->dy[o];
         hfilt[i] = f;
         horig[i] = o;
-        hoff[i] = pfull[2 * f];
-        hcnt[i] = pfull[2 * f + 1];
-        hcoff[i] = pcomp[2 * f];
-        hccnt[i] = pcomp[2 * f + 1];
-        htmin[i] = pcomp[2 * f + 1] > 0 ? ptmin[f] : INFINITY;
         samples += pr->tab_off[f + 1] - pr->tab_off[f];
     }
     for (int i = 0; i < N; ++i) lognorm += std::log(2. * M_PI * pr->dy[i] * pr->dy[i]);  // caller order, like np.sum
@@ -949,13 +1084,14 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     }
     std::vector<int> htaboff(pfull);
     if (htab.empty()) htab.push_back(make_double2(1., 0.));
-    std::vector<int4> hdesc(N);
-    std::vector<double> hinvdy(N), hinvtmin(N);
-    for (int i = 0; i < N; ++i) {
-        hdesc[i] = make_int4(hoff[i], hcnt[i], hcoff[i], hccnt[i]);
-        hinvdy[i] = 1. / hdy[i];
-        hinvtmin[i] = hccnt[i] > 0 ? 1. / htmin[i] : 0.;  // t_min = 0 -> inf: always valid
-    }
+    std::vector<double> hinvdy(N);
+    for (int i = 0; i < N; ++i) hinvdy[i] = 1. / hdy[i];
+    std::vector<FiltDesc> hfd(NF);  // per filter: where its tables are and from which temperature each is valid
+    for (int f = 0; f < NF; ++f)
+        hfd[f] = FiltDesc{pfull[2 * f], pfull[2 * f + 1], pcomp[2 * f], pcomp[2 * f + 1], phot[2 * f], phot[2 * f + 1],
+                          0, 0,
+                          pcomp[2 * f + 1] > 0 ? 1. / ptmin[f] : 0.,  // t_min = 0 -> inf: always valid
+                          phot[2 * f + 1] > 0 ? 1. / ptmin2[f] : 0.};
     std::vector<double> hexp(kExpTabSize);
     for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
 
@@ -966,6 +1102,20 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_parts = n_parts;
     dp.cpb = cpb;
     for (int j = 0; j <= kMaxParts; ++j) dp.part_start[j] = part_start[j];
+    e->max_part_epochs = 0;
+    for (int j = 0; j <= kMaxParts; ++j)  // epochs were sorted, so a part's epoch range starts at its first point's
+        dp.part_ep0[j] = (j < n_parts && part_start[j] < N && all_finite_t) ? ep_of[order[part_start[j]]]
+                                                                              : (int)epochs.size();
+    if (all_finite_t && N > 0) {
+        // `order` is filter-sorted inside a part: the part's first epoch is the minimum over its points
+        for (int j = 0; j < n_parts; ++j) {
+            int lo = (int)epochs.size();
+            for (int i = part_start[j]; i < part_start[j + 1]; ++i) lo = std::min(lo, hepoch[i]);
+            dp.part_ep0[j] = lo;
+        }
+        for (int j = 0; j < n_parts; ++j)
+            e->max_part_epochs = std::max(e->max_part_epochs, dp.part_ep0[j + 1] - dp.part_ep0[j]);
+    }
     dp.n_tab = (int)htab.size();
     dp.n_filters = NF;
     dp.n_dim = n_dim;
@@ -974,7 +1124,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.sigma_abs = pr->sigma_type == LCF_SIGMA_ABSOLUTE;
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
-    dp.tab_in_lds = (int)htab.size() <= kLdsTabMax;
+    dp.tab_in_lds = (int)htab.size() <= kLdsTabMax && NF <= kLdsFiltMax;
     if (reddened && !dp.tab_in_lds)
         return bail(fail(LCF_ERR_UNSUPPORTED, "ShockCooling3: the band tables must fit in LDS"));
     dp.n_epochs = (int)epochs.size();
@@ -986,7 +1136,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
-    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? htab.size() * sizeof(double2) : 0);
+    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) +
+                   (dp.tab_in_lds ? htab.size() * sizeof(double2) + NF * sizeof(FiltDesc) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
     int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
@@ -1001,13 +1152,12 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         dp.tab_ext = dext;
     }
     int* depoch;
-    int4* ddesc;
-    double *dexp, *depocht, *dinvdy, *dinvtmin;
+    FiltDesc* dfd;
+    double *dexp, *depocht, *dinvdy;
     UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
-    UP(hdesc, ddesc); UP(hinvdy, dinvdy); UP(hinvtmin, dinvtmin); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
-    dp.pt_desc = ddesc;
+    UP(hfd, dfd); UP(hinvdy, dinvdy); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
+    dp.f_desc = dfd;
     dp.inv_dy = dinvdy;
-    dp.pt_inv_tmin = dinvtmin;
     dp.pt_epoch = depoch;
     dp.epoch_t = depocht;
     dp.exp2tab = dexp;
@@ -1169,7 +1319,7 @@ struct lcf_sampler {
     lcf_engine* e = nullptr;
     DevSampler ds{};
     std::vector<void*> owned;
-    double *coef = nullptr, *lprior = nullptr, *part = nullptr;
+    double *coef = nullptr, *lprior = nullptr;
     double2* therm = nullptr;
     int* d_perm = nullptr;
     int64_t perm_rows = 0;  // rows allocated
@@ -1250,14 +1400,61 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
 lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool finalize, hipStream_t st) {
     lcf_engine* e = s->e;
     if (hi <= lo) return LCF_OK;
-    launch_points<0>(e, lo, hi - lo, s->ds.Q[(s->g_next - 1) & 1], s->coef, s->lprior, s->therm, s->part, nullptr, st,
+    double* part = s->ds.part2[(s->g_next - 1) & 1];
+    launch_points<0>(e, lo, hi - lo, s->ds.Q[(s->g_next - 1) & 1], s->coef, s->lprior, s->therm, part, nullptr, st,
                      !thermal_done);
     if (finalize) {
         const int bs = 128;
         hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
-                           s->part + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
+                           part + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
     }
     LCF_HIP(hipGetLastError());
+    return LCF_OK;
+}
+
+size_t fused_lds_bytes(const lcf_engine* e) {
+    return e->lds_bytes + kFusedScratch * sizeof(double) +
+           (e->dp.use_therm ? (size_t)e->max_part_epochs * sizeof(double2) : 0);
+}
+
+bool fused_eligible(const lcf_sampler* s) {
+    static const bool disabled = std::getenv("LCF_NO_FUSED") != nullptr;
+    const lcf_engine* e = s->e;
+    return !disabled && e->dp.tab_in_lds && fused_lds_bytes(e) <= 64 * 1024;
+}
+
+// One launch for a whole half-step of a single-GPU run: commit half-step g_next - 1 (if pending), draw half-step
+// g_next and evaluate its likelihood.
+lcf_status launch_fused(lcf_sampler* s, hipStream_t st) {
+    lcf_engine* e = s->e;
+    const DevSampler& ds = s->ds;
+    const long long g = s->g_next;
+    const int have_prev = s->pending ? 1 : 0;
+    const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
+    const long long rel = g - s->g_run0;
+    const DrawRec* draws = s->d_draws + (size_t)rel * ds.n_half;
+    const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
+    const dim3 grid((unsigned)((size_t)ds.n_half * e->dp.n_parts));
+    const size_t lds = fused_lds_bytes(e);
+#define LCF_FUSED3(ND, V, T) hipLaunchKernelGGL((k_fused<ND, V, T>), grid, dim3(kBlock), lds, st, e->dp, ds, have_prev,  \
+                                                prev_row, draws, prev_draws, g)
+#define LCF_FUSED(ND)                                                                             \
+    do {                                                                                          \
+        if (e->dp.variant == 0) { if (e->dp.use_therm) LCF_FUSED3(ND, 0, true); else LCF_FUSED3(ND, 0, false); } \
+        else { if (e->dp.use_therm) LCF_FUSED3(ND, 1, true); else LCF_FUSED3(ND, 1, false); }      \
+    } while (0)
+    switch (ds.n_dim) {
+        case 4: LCF_FUSED(4); break;
+        case 5: LCF_FUSED(5); break;
+        case 6: LCF_FUSED(6); break;
+        case 8: LCF_FUSED(8); break;
+        default: LCF_FUSED(0); break;
+    }
+#undef LCF_FUSED
+#undef LCF_FUSED3
+    LCF_HIP(hipGetLastError());
+    s->pending = true;
+    s->g_next = g + 1;
     return LCF_OK;
 }
 
@@ -1292,10 +1489,10 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     for (int b = 0; b < 2; ++b) {
         AL(ds.Q[b], nh * nd); AL(ds.rec[b], nh); AL(ds.newlp[b], nh);
     }
-    AL(s->coef, nh * kNCoef); AL(s->lprior, nh); AL(s->part, nh * e->dp.n_parts);
+    AL(s->coef, nh * kNCoef); AL(s->lprior, nh);
+    for (int b = 0; b < 2; ++b) AL(ds.part2[b], nh * e->dp.n_parts);
     if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
-    ds.part = s->part;
     LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
     LCF_HIP(hipEventCreate(&s->ev0));
@@ -1587,8 +1784,14 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     hipStream_t st = s->e->stream;
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
-    // per half-step: [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
+    // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else
+    // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
+    const bool fused = fused_eligible(s);
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
+        if (fused) {
+            if (lcf_status r = launch_fused(s, st)) return r;
+            continue;
+        }
         if (lcf_status r = launch_next(s, true, true, 0, s->ds.n_half, st)) return r;
         if (lcf_status r = launch_eval(s, 0, s->ds.n_half, s->e->dp.use_therm != 0, false, st)) return r;
     }
@@ -1646,7 +1849,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         lcf_sampler* s = ss[t];
         s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
         s->ds.inline_finalize = 1;
-        items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm, s->part};
+        items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm};
         // With many transients in one launch a single workgroup per proposal already fills the chip, and it stages
         // the tables and reduces once for all of the proposal's chunks: fewer parts than the engine's default.
         DevProblem& ip = items[t].pb;

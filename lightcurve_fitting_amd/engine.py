@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 3
+LCF_ABI_VERSION = 4
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -45,6 +45,7 @@ class LcfProblem(C.Structure):
                 ('consts', C.c_double * N_CONSTS),
                 ('t', _dp), ('y', _dp), ('dy', _dp), ('filt_idx', _ip), ('tab_off', _ip), ('tab_a', _dp),
                 ('tab_w', _dp), ('tab_ext', _dp), ('ctab_off', _ip), ('ctab_a', _dp), ('ctab_w', _dp), ('ctab_tmin', _dp),
+                ('htab_off', _ip), ('htab_a', _dp), ('htab_w', _dp), ('htab_tmin', _dp),
                 ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
                 ('n_knots', C.c_int32), ('reserved', C.c_int32), ('spline_knots', _dp), ('spline_coef', _dp),
                 ('priors', C.POINTER(LcfPrior))]
@@ -161,7 +162,8 @@ class Engine:
     ``(kind, p_min, p_max, mean, stddev)`` or ``None``."""
 
     def __init__(self, model_id, n_par, consts, t, y, dy, filt_idx, tab_off, tab_a, tab_w, use_sigma=False,
-                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None, tab_ext=None):
+                 sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None, tab_ext=None,
+                 htab=None):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -193,6 +195,12 @@ class Engine:
                 raise ValueError('inconsistent compressed tables')
             keep += cx
             pr.ctab_off, pr.ctab_a, pr.ctab_w, pr.ctab_tmin = _ptr(cx[0], _ip), _ptr(cx[1]), _ptr(cx[2]), _ptr(cx[3])
+        if htab is not None:  # (hoff, ha, hw, htmin): the shorter "hot" level (needs ctab)
+            hx = [_i32(htab[0]), _f64(htab[1]), _f64(htab[2]), _f64(htab[3])]
+            if len(hx[0]) != pr.n_filters + 1 or len(hx[3]) != pr.n_filters or len(hx[1]) != len(hx[2]):
+                raise ValueError('inconsistent hot-level tables')
+            keep += hx
+            pr.htab_off, pr.htab_a, pr.htab_w, pr.htab_tmin = _ptr(hx[0], _ip), _ptr(hx[1]), _ptr(hx[2]), _ptr(hx[3])
         if companion is not None:
             kp, sp, dtp, knots, coef = companion
             extra = [_i32(kp), _i32(sp), _i32(dtp), _f64(knots), _f64(coef)]

@@ -87,6 +87,9 @@ def gauss_rule(x, w, m):
 
 #: relative accuracy the compressed band sum must reach against the full sum wherever it is used
 COMPRESSION_TOL = 2e-14
+#: lowest temperatures [kK] down to which the two compressed levels must hold (see PackedTables)
+COOL_TMIN = 2.0
+HOT_TMIN = 6.0
 _T_GRID = np.geomspace(0.2, 2e4, 101)
 
 
@@ -351,25 +354,39 @@ class PackedTables:
         self.off = np.asarray(off, dtype=np.int32)
         self.z = z
         self.cutoff_freq = cutoff_freq
-        # Gauss-compressed companions (empty slice + t_min = inf where a filter is too narrow to gain)
-        ca, cw, coff, tmin = [], [], [0], []
+        # Gauss-compressed companions, two levels (empty slice + t_min = inf where a level gains nothing):
+        #   "cool": the shortest rule good down to COOL_TMIN (2 kK) -- cold photospheres rarely need the full table;
+        #   "hot":  a still shorter one good down to HOT_TMIN (6 kK) at most -- where most of a fit's points are.
+        # A level is kept only if it saves at least one quad of samples against the next longer table.
+        def quads(n):
+            return (n + 3) // 4
+
+        levels = {'c': ([], [], [0], []), 'h': ([], [], [0], [])}
         for i in range(len(self.filters)):
             a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
-            if os.environ.get('LCF_EXPERIMENT_HOT') == '1':
-                comp = compress_planck_table(a, w, orders=(8,), max_tmin=6., min_ratio=1.1) if compress else None
-            else:
-                comp = compress_planck_table(a, w) if compress and len(a) >= 24 else None
-            if comp is None:
-                tmin.append(np.inf)
-            else:
-                ca.append(comp[0])
-                cw.append(comp[1])
-                tmin.append(comp[2])
-            coff.append(coff[-1] + (0 if comp is None else len(comp[0])))
-        self.ca = np.concatenate(ca) if ca else np.zeros(0)
-        self.cw = np.concatenate(cw) if cw else np.zeros(0)
-        self.coff = np.asarray(coff, dtype=np.int32)
-        self.ctmin = np.asarray(tmin, dtype=np.float64)
+            cool = compress_planck_table(a, w, orders=(8, 12, 16, 24, 32), max_tmin=COOL_TMIN,
+                                         min_ratio=1.) if compress else None
+            if cool is not None and quads(len(cool[0])) >= quads(len(a)):
+                cool = None
+            longer = len(a) if cool is None else len(cool[0])
+            hot = compress_planck_table(a, w, orders=(8,), max_tmin=HOT_TMIN, min_ratio=1.) if compress else None
+            if hot is not None and (quads(len(hot[0])) >= quads(longer) or (cool is not None and hot[2] <= cool[2])):
+                hot = None
+            for key, comp in (('c', cool), ('h', hot)):
+                aa, ww, oo, tt = levels[key]
+                if comp is None:
+                    tt.append(np.inf)
+                else:
+                    aa.append(comp[0])
+                    ww.append(comp[1])
+                    tt.append(comp[2])
+                oo.append(oo[-1] + (0 if comp is None else len(comp[0])))
+        for key, names in (('c', ('ca', 'cw', 'coff', 'ctmin')), ('h', ('ha', 'hw', 'hoff', 'htmin'))):
+            aa, ww, oo, tt = levels[key]
+            setattr(self, names[0], np.concatenate(aa) if aa else np.zeros(0))
+            setattr(self, names[1], np.concatenate(ww) if ww else np.zeros(0))
+            setattr(self, names[2], np.asarray(oo, dtype=np.int32))
+            setattr(self, names[3], np.asarray(tt, dtype=np.float64))
 
     def index(self, f):
         return self.filters.index(as_filter(f))

@@ -182,6 +182,7 @@ class Model:
                            use_sigma=use_sigma, sigma_type=st, priors=pri,
                            companion=self._companion_tables(uniq), device=self.device if device is None else device,
                            ctab=None if self.reddened else (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
+                           htab=None if self.reddened else (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin),
                            tab_ext=tabs.ext)
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):
@@ -505,7 +506,7 @@ def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0.):
         tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
         ctab = (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin)
     eng = _eng.Engine(_eng.MODEL_BLACKBODY, 2, [], np.zeros(1), np.zeros(1), np.ones(1), np.zeros(1, dtype=np.int32),
-                      tabs.off, tabs.a, tabs.w, ctab=ctab)
+                      tabs.off, tabs.a, tabs.w, ctab=ctab)  # (pointwise kernel: cool level only)
     try:
         if T.ndim == 1 and len(T) == len(filts):
             return eng.blackbody_to_filters(idx, T, R)

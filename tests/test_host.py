@@ -55,19 +55,29 @@ def test_gauss_compressed_tables_reproduce_the_full_band_sum():
     validity threshold, and against the reference's synthesize() numbers."""
     names = [f.name for f in F.all_filters if f.filename]
     tabs = F.PackedTables(names, z=0.002)
-    n_comp = 0
+    n_comp = n_hot = 0
     for i, n in enumerate(names):
         a, w = tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]]
-        ca, cw = tabs.ca[tabs.coff[i]:tabs.coff[i + 1]], tabs.cw[tabs.coff[i]:tabs.coff[i + 1]]
-        if len(ca) == 0:
-            assert np.isinf(tabs.ctmin[i])
-            continue
-        n_comp += 1
-        assert len(ca) <= len(a) // 2 and np.all(cw > 0) and np.all(ca > 0) and np.all(np.diff(ca) < 0)
-        assert np.sum(cw) == pytest.approx(np.sum(w), rel=1e-13)
-        for T in np.concatenate([[max(tabs.ctmin[i], 0.3)], np.geomspace(max(tabs.ctmin[i], 0.3), 5e3, 23)]):
-            full, comp = np.sum(w / np.expm1(a / T)), np.sum(cw / np.expm1(ca / T))
-            assert abs(comp - full) <= 4e-14 * full, (n, T)
+        longer = len(a)
+        for lvl, (oo, aa, ww, tt, floor) in enumerate([(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin, F.COOL_TMIN),
+                                                      (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin, F.HOT_TMIN)]):
+            ca, cw = aa[oo[i]:oo[i + 1]], ww[oo[i]:oo[i + 1]]
+            if len(ca) == 0:
+                assert np.isinf(tt[i])
+                continue
+            n_comp += lvl == 0
+            n_hot += lvl == 1
+            # a level must save at least one quad of samples against the next longer table, and hold from its t_min
+            assert (len(ca) + 3) // 4 < (longer + 3) // 4 and tt[i] <= floor * 1.13  # (one grid step of margin)
+            assert np.all(cw > 0) and np.all(ca > 0) and np.all(np.diff(ca) < 0)
+            assert np.sum(cw) == pytest.approx(np.sum(w), rel=1e-13)
+            for T in np.concatenate([[max(tt[i], 0.3)], np.geomspace(max(tt[i], 0.3), 5e3, 23)]):
+                full, comp = np.sum(w / np.expm1(a / T)), np.sum(cw / np.expm1(ca / T))
+                assert abs(comp - full) <= 4e-14 * full, (n, lvl, T)
+            longer = len(ca)
+        if np.isfinite(tabs.htmin[i]) and np.isfinite(tabs.ctmin[i]):
+            assert tabs.htmin[i] >= tabs.ctmin[i]  # the engine tests the hot level first
+    assert n_hot >= 10
     assert n_comp >= 50
     p = golden('primitives')
     for i, n in enumerate([str(x) for x in p['synth/names']]):
