@@ -581,10 +581,9 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
                 for (int d = 0; d < kD; ++d)
                     if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
                 sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
-                if (coef) {
+                if (coef)
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
-                    lprior[i] = lpr;
-                }
+                if (lprior) lprior[i] = lpr;
             }
         }
     }
@@ -678,7 +677,8 @@ __device__ inline double uniform_f64(double v) {
 template <int ND, int VARIANT, bool THERM>
 __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb, const DevSampler sm, int have_prev,
                                                   long long prev_row, const DrawRec* __restrict__ draws,
-                                                  const DrawRec* __restrict__ prev_draws, long long g) {
+                                                  const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
+                                                  double* __restrict__ lprior) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;
@@ -687,13 +687,23 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     double* sc = reinterpret_cast<double*>(ltab + pb.n_tab + 3 * pb.n_filters);
     double* sq = sc + kNCoef + 2;
     double2* lth = reinterpret_cast<double2*>(sc + kFusedScratch);
-    const int nh = sm.n_half;
-    const int part = blockIdx.x / nh, i = blockIdx.x % nh;
     const int tid = threadIdx.x;
+    // Multi-GPU: this rank evaluates the slots [lo, hi) only.  Every other slot (commit + light proposal, no
+    // likelihood) takes one WAVE of the workgroups launched behind the shard's own.
+    const int n_own = hi - lo;
+    if ((int)blockIdx.x >= n_own * pb.n_parts) {
+        const int k = ((int)blockIdx.x - n_own * pb.n_parts) * (kBlock / 64) + (tid >> 6);
+        const int slot = k < lo ? k : k + n_own;
+        if (slot < sm.n_half)
+            step_serial<ND>(pb, sm, slot, true, tid & 63, have_prev, prev_row, 1, draws, prev_draws, g, false, nullptr,
+                            nullptr, nullptr, nullptr);
+        return;
+    }
+    const int part = blockIdx.x / n_own, i = lo + blockIdx.x % n_own;
     const bool reddened = pb.model == kShockCooling3;
     if (tid < 64)
         step_serial<ND>(pb, sm, i, part == 0, tid, have_prev, prev_row, 1, draws, prev_draws, g, true, sc, sq, nullptr,
-                        nullptr);
+                        lprior);
     else if (!reddened)
         stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kBlock - 64);
     __syncthreads();
@@ -1425,7 +1435,7 @@ bool fused_eligible(const lcf_sampler* s) {
 
 // One launch for a whole half-step of a single-GPU run: commit half-step g_next - 1 (if pending), draw half-step
 // g_next and evaluate its likelihood.
-lcf_status launch_fused(lcf_sampler* s, hipStream_t st) {
+lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
     lcf_engine* e = s->e;
     const DevSampler& ds = s->ds;
     const long long g = s->g_next;
@@ -1434,10 +1444,12 @@ lcf_status launch_fused(lcf_sampler* s, hipStream_t st) {
     const long long rel = g - s->g_run0;
     const DrawRec* draws = s->d_draws + (size_t)rel * ds.n_half;
     const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
-    const dim3 grid((unsigned)((size_t)ds.n_half * e->dp.n_parts));
+    const int foreign = ds.n_half - (hi - lo);
+    const dim3 grid((unsigned)((size_t)(hi - lo) * e->dp.n_parts + (foreign + kBlock / 64 - 1) / (kBlock / 64)));
     const size_t lds = fused_lds_bytes(e);
+    double* lprior = ds.inline_finalize ? nullptr : s->lprior;  // the finalize launch of a sharded run reads it
 #define LCF_FUSED3(ND, V, T) hipLaunchKernelGGL((k_fused<ND, V, T>), grid, dim3(kBlock), lds, st, e->dp, ds, have_prev,  \
-                                                prev_row, draws, prev_draws, g)
+                                                prev_row, draws, prev_draws, g, lo, hi, lprior)
 #define LCF_FUSED(ND)                                                                             \
     do {                                                                                          \
         if (e->dp.variant == 0) { if (e->dp.use_therm) LCF_FUSED3(ND, 0, true); else LCF_FUSED3(ND, 0, false); } \
@@ -1456,6 +1468,27 @@ lcf_status launch_fused(lcf_sampler* s, hipStream_t st) {
     s->pending = true;
     s->g_next = g + 1;
     return LCF_OK;
+}
+
+// Log-posteriors of the shard's proposals from their partial sums (sharded runs: the all-gather sends these).
+lcf_status launch_finalize(lcf_sampler* s, int lo, int hi, hipStream_t st) {
+    if (hi <= lo) return LCF_OK;
+    lcf_engine* e = s->e;
+    const int par = (int)((s->g_next - 1) & 1), bs = 128;
+    hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
+                       s->ds.part2[par] + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[par] + lo);
+    LCF_HIP(hipGetLastError());
+    return LCF_OK;
+}
+
+// One half-step of a sharded run on this rank, up to the log-posteriors of its shard [lo, hi).
+lcf_status launch_half_step_sharded(lcf_sampler* s, int lo, int hi, hipStream_t st) {
+    if (fused_eligible(s) && hi > lo) {
+        if (lcf_status r = launch_fused(s, lo, hi, st)) return r;
+        return launch_finalize(s, lo, hi, st);
+    }
+    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
+    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st);  // launch_next computed the thermal states
 }
 
 lcf_status flush_pending(lcf_sampler* s, hipStream_t st) {
@@ -1645,9 +1678,7 @@ lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int
     if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
     hipStream_t st = stream ? (hipStream_t)stream : s->e->stream;
     s->ds.inline_finalize = 0;
-    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-    const bool fused = s->e->dp.use_therm != 0;  // launch_next computed the shard's thermal states
-    return launch_eval(s, lo, hi, fused, true, st);
+    return launch_half_step_sharded(s, lo, hi, st);
 }
 
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
@@ -1763,9 +1794,7 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
     LCF_HIP(hipEventRecord(s->ev0, st));
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
-        if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-        const bool fused = s->e->dp.use_therm != 0;
-        if (lcf_status r = launch_eval(s, lo, hi, fused, true, st)) return r;
+        if (lcf_status r = launch_half_step_sharded(s, lo, hi, st)) return r;
         double* buf = s->ds.newlp[(s->g_next - 1) & 1];
         if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo, buf, (size_t)width, /*ncclDouble*/ 8, c->comm, st),
                                       "ncclAllGather"))
@@ -1789,7 +1818,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     const bool fused = fused_eligible(s);
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
         if (fused) {
-            if (lcf_status r = launch_fused(s, st)) return r;
+            if (lcf_status r = launch_fused(s, 0, s->ds.n_half, st)) return r;
             continue;
         }
         if (lcf_status r = launch_next(s, true, true, 0, s->ds.n_half, st)) return r;
