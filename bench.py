@@ -63,26 +63,41 @@ def initial_walkers(n):
 
 def committed_pmc(variant):
     """HBM traffic and VALU utilisation of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_k_points_v<variant>.json, collected by tools/collect_profiles.sh; counters cannot be read from
+    (profiles/r01_pmc_k_fused_v<variant>.json, collected by tools/collect_profiles.sh; counters cannot be read from
     inside this process).  FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads
-    prescribes (MI355X_MICROARCH.md, HBM section); both are in KiB per launch of 512 walkers."""
-    path = os.path.join(ROOT, 'profiles', f'r01_pmc_k_points_v{variant}.json')
+    prescribes (MI355X_MICROARCH.md, HBM section); both are in KiB per launch of 512 proposals."""
+    path = os.path.join(ROOT, 'profiles', f'r01_pmc_k_fused_v{variant}.json')
     try:
         c = {k: v['mean_per_launch'] for k, v in json.load(open(path)).items()}
         traffic = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.
         # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; the SQ counters cover
-        # SQ_WAVES of the launched waves (512 walkers x 4 workgroups x 4 waves)
-        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 4 * 4))
+        # SQ_WAVES of the launched waves (512 proposals x 2 workgroups x 4 waves)
+        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 2 * 4))
         return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES']
     except Exception:
         return None, None, None
 
 
+def fused_kernel_ms(engine, x0, reps=100):
+    """Average duration of the dominant kernel, k_fused (one launch = one half-step of a 1024-walker ensemble =
+    512 proposals: commit + draw + thermal states + likelihood), from HIP events on the engine's stream around
+    `reps` steps = 2*reps back-to-back launches (plus one trailing 5-us commit launch, i.e. < 0.03 us per launch)."""
+    from lightcurve_fitting_amd.engine import NativeSampler
+    s = NativeSampler(engine, WALKERS_PER_GPU, SEED + 7)
+    s.set_state(x0[:WALKERS_PER_GPU])
+    s.run(0, 10, 'random', False)
+    s.run(10, reps, 'random', False)
+    ms = s.last_run_ms() / (2 * reps)
+    s.close()
+    return ms
+
+
 def roofline_entry(engine, x0, shard, variant):
-    """Dominant kernel alone (HIP events on the engine's stream, 50 back-to-back launches) against the FP64 VALU
-    ceiling by the ALGORITHMIC instruction count of SURVEY 8d."""
+    """Dominant kernel (HIP events on the engine's stream, 200 back-to-back launches) against the FP64 VALU ceiling
+    by the ALGORITHMIC instruction count of SURVEY 8d."""
     engine.set_variant(variant)
-    kern_ms = engine.profile_loglike_kernel(x0[:shard], reps=50)
+    shard = WALKERS_PER_GPU // 2
+    kern_ms = fused_kernel_ms(engine, x0)
     evals_per_s = shard / (kern_ms * 1e-3)
     achieved = evals_per_s * ALG_INSTR / 1e12
     hbm_gbs = evals_per_s * ALG_BYTES / 1e9
@@ -91,8 +106,8 @@ def roofline_entry(engine, x0, shard, variant):
             'frac': achieved / PEAK_FP64_TINSTR, 'traffic': traffic,
             'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
             'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
-            'kernel': 'k_points<1,0,true,true>', 'band_sum_variant': variant, 'kernel_ms': kern_ms,
-            'walkers_per_launch': shard,
+            'kernel': 'k_fused<5,1,true> (a whole half-step: commit + proposal + thermal states + likelihood)',
+            'band_sum_variant': variant, 'kernel_ms': kern_ms, 'walkers_per_launch': shard,
             'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
                     'algorithmic_bytes_per_walker_step': ALG_BYTES}}
 
@@ -380,9 +395,9 @@ def main():
         roof['note'] = ('FP64 vector-ALU lane-instructions, ALGORITHMIC count: 34 per Planck sample of the reference '
                         "(146000 per evaluation) + 68 per point (SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 "
                         'TFLOP/s FMA. frac exceeds 1 because the kernel needs far fewer instructions than the '
-                        'convention: ~19 per sample, and with the Gauss-compressed tables (variant 2) 12 samples '
-                        'reproduce the sum over 87 to 2e-14. valu_utilisation_pmc is the measured busy fraction of '
-                        'the vector ALU.')
+                        'convention: ~19 per sample, and with the Gauss-compressed tables (variant 2) 8 samples '
+                        'reproduce the sum over up to 87 to 2e-14 above ~5 kK (12-16 below). '
+                        'valu_utilisation_pmc is the measured busy fraction of the vector ALU.')
         roof_full = roofline_entry(engine, x0, shard, 1) if (args.full_tables_reference and args.variant != 1) else None
         engine.set_variant(args.variant)
         out = {

@@ -88,7 +88,7 @@ def gauss_rule(x, w, m):
 #: relative accuracy the compressed band sum must reach against the full sum wherever it is used
 COMPRESSION_TOL = 2e-14
 #: lowest temperatures [kK] down to which the two compressed levels must hold (see PackedTables)
-COOL_TMIN = 2.0
+COOL_TMIN = 1.0
 HOT_TMIN = 6.0
 _T_GRID = np.geomspace(0.2, 2e4, 101)
 
@@ -355,7 +355,7 @@ class PackedTables:
         self.z = z
         self.cutoff_freq = cutoff_freq
         # Gauss-compressed companions, two levels (empty slice + t_min = inf where a level gains nothing):
-        #   "cool": the shortest rule good down to COOL_TMIN (2 kK) -- cold photospheres rarely need the full table;
+        #   "cool": the shortest rule good down to COOL_TMIN (1 kK) -- cold photospheres rarely need the full table;
         #   "hot":  a still shorter one good down to HOT_TMIN (6 kK) at most -- where most of a fit's points are.
         # A level is kept only if it saves at least one quad of samples against the next longer table.
         def quads(n):

@@ -14,7 +14,7 @@ i=0
 for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
          "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/v${V}_pmc$i -- python3 $R/tools/prof_kernel.py 5 $V > $OUT/v${V}_pmc$i.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $OUT/v${V}_pmc$i -- python3 $R/tools/prof_kernel.py 3 $V > $OUT/v${V}_pmc$i.log 2>&1
 done
 python3 - "$OUT" "$V" <<'PY'
 import csv, glob, collections, json, sys
@@ -23,14 +23,14 @@ res = {}
 for p in sorted(glob.glob(out + f'/v{variant}_pmc*/*/*_counter_collection.csv')):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if 'k_points' in r['Kernel_Name']:
+        if 'k_fused' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         res[k] = {'mean_per_launch': sum(v) / len(v), 'launches': len(v)}
-json.dump(res, open(out + f'/pmc_k_points_v{variant}.json', 'w'), indent=1)
+json.dump(res, open(out + f'/pmc_k_fused_v{variant}.json', 'w'), indent=1)
 print(variant, json.dumps(res))
 PY
 done
-cp $OUT/pmc_k_points_v*.json $R/profiles/ 2>/dev/null; for f in $R/profiles/pmc_k_points_v*.json; do mv $f $R/profiles/r01_$(basename $f); done
+for f in $OUT/pmc_k_fused_v*.json; do cp $f $R/profiles/${TAG}_$(basename $f); done
 python3 $R/bench.py --steps 1000 --warmup 20 --full-tables-reference > $OUT/bench_unprofiled.json 2> /dev/null
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv

@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT
 for lib in $R/build_variants/*.so; do
-  for tag in fused nofused; do
+  for tag in fused; do
     if [ $tag = nofused ]; then export LCF_NO_FUSED=1; else unset LCF_NO_FUSED; fi
     LCF_HIP_LIB=$lib python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/bv.log 2>&1
     python3 -c "
