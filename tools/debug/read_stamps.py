@@ -1,17 +1,29 @@
-import os, sys, ctypes as C
+"""Median s_memtime ticks between the stamps of tools/debug/make_stamp_build.py (run with
+LCF_HIP_LIB=build_variants/liblcf_stamps.so on the GPU box)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-import bench
-from lightcurve_fitting_amd import engine as E
-from lightcurve_fitting_amd.sampler import EnsembleSampler
+import bench  # noqa: E402
+from lightcurve_fitting_amd import engine as E  # noqa: E402
+from lightcurve_fitting_amd.sampler import EnsembleSampler  # noqa: E402
+
 model, lc, priors = bench.build_problem(0)
 eng = model.engine_for(lc, priors=priors)
 s = EnsembleSampler(1024, 5, eng, seed=1)
 s.run_mcmc(bench.initial_walkers(1024), 50, store=False)
 lib = E.load_library()
-buf = (C.c_ulonglong * (64*12))()
-lib.lcf_debug_read_stamps.argtypes=[C.c_void_p]; lib.lcf_debug_read_stamps(buf)
-a = np.array(buf[:], dtype=np.int64).reshape(64,12)
-d = np.diff(a[:, :11], axis=1)
-print('median cycles per segment (s_memtime ticks):', np.median(d, axis=0))
-print('total', np.median(a[:,10]-a[:,0]), 'to stamp8', np.median(a[:,8]-a[:,0]))
+buf = (C.c_ulonglong * (64 * 12))()
+lib.lcf_debug_read_stamps.argtypes = [C.c_void_p]
+lib.lcf_debug_read_stamps(buf)
+a = np.array(buf[:], dtype=np.int64).reshape(64, 12)[:, :11]
+names = ['entry->draw record', 'accept tests', 'proposal', 'logarithms', 'coefficients', 'priors + LDS publish',
+         'barrier', 'coefficients to SGPRs + thermal states', 'points', 'reduction']
+d = np.diff(a, axis=1)
+for n, v in zip(names, np.median(d, axis=0)):
+    print(f'{n:45s} {v:9.0f}')
+print('total', np.median(a[:, 10] - a[:, 0]), ' spread of entry stamps over the 64 workgroups', np.ptp(a[:, 0]))
+print('device ms per step', s.last_run_ms / 50)
