@@ -394,3 +394,25 @@ def test_shockcooling3_distance_and_reddening():
                                    priors=[p.descriptor() for p in priors]))
     ref, ref_lp, _ = O.stretch_move_run(fn, x0, 5, 5)
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
+
+
+def test_model_grid_at_plotting_size():
+    """The second caller of the kernel: `lightcurve_model_plot` evaluates
+    model(xfit[1000], ufilts, *ps[ndim, 100]) -> (nfilt, 1000, 100) (fitting.py:337-352; dense branch,
+    models.py:1163-1164)."""
+    import time
+    rng = np.random.default_rng(12)
+    m = M.ShockCooling(redshift=0.01)
+    xfit = np.linspace(0.3, 12., 1000)
+    ufilts = list('UBVgri')
+    ps = np.array([1.2, 0.5, 3.0, 2.0, 0.1]) * (1. + 0.2 * rng.uniform(-1., 1., (100, 5)))
+    got = m(xfit, ufilts, *ps.T)                       # first call builds the 6000-point evaluation engine
+    t0 = time.perf_counter()
+    got = m(xfit, ufilts, *ps.T)
+    dt = time.perf_counter() - t0
+    assert got.shape == (6, 1000, 100)
+    orc = ('ShockCooling', O.ShockCoolingOracle(0.01))
+    for j, f in enumerate(ufilts):
+        want = O.evaluate(orc, xfit, [O.band(f)] * len(xfit), ps.T)      # (1000, 100)
+        assert relerr(got[j], want) < TOL
+    print(f'model grid 6 x 1000 x 100: {dt * 1e3:.2f} ms per call (host arrays in and out)')
