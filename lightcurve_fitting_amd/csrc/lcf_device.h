@@ -65,6 +65,7 @@ struct DevProblem {
     int pad4[2];
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
+    double knot_inv_h;      // 1 / spacing of the spline knots when they are equally spaced (to 1e-9), else 0
     double sigma_unit_abs;  // median(dy)
     // points, ordered by (part, filter)
     const double* t;
@@ -348,13 +349,24 @@ __device__ inline double walker_log_prior(const DevProblem& pb, const double* __
 }
 
 // Piecewise-cubic SiFTO template, 0 outside the knot range (and for NaN arguments).  models.py:717, 816-826
+// `inv_h` > 0: the knots are (nearly) equally spaced, h = 1 / inv_h apart -- the interval is then computed and
+// corrected against the neighbouring knots instead of searched (the SiFTO template: 103 knots one day apart).
 __device__ inline double spline_eval(const double* __restrict__ knots, int nk, const double* __restrict__ coef,
-                                     double x) {
-    if (!(x >= knots[0] && x <= knots[nk - 1])) return 0.;
-    int lo = 0, hi = nk - 1;  // invariant: knots[lo] <= x <= knots[hi]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (x >= knots[mid]) lo = mid; else hi = mid;
+                                     double x, double inv_h) {
+    const double k0 = knots[0];
+    if (!(x >= k0 && x <= knots[nk - 1])) return 0.;
+    int lo;  // the interval of x: the largest lo <= nk - 2 with knots[lo] <= x
+    if (inv_h > 0.) {
+        lo = min(max((int)((x - k0) * inv_h), 0), nk - 2);
+        while (lo < nk - 2 && x >= knots[lo + 1]) ++lo;
+        while (lo > 0 && x < knots[lo]) --lo;
+    } else {
+        int hi = nk - 1;  // invariant: knots[lo] <= x <= knots[hi]
+        lo = 0;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (x >= knots[mid]) lo = mid; else hi = mid;
+        }
     }
     const double dx = x - knots[lo];
     const double* q = coef + 4 * lo;

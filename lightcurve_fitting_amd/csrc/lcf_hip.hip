@@ -107,7 +107,7 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
         const double sfac = sp >= 0 ? p[sp] : 1.;
         const double dt = dp >= 0 ? p[dp] : 0.;
         const double x = (t_in - c[3] - dt) / c[4];
-        const double tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x);
+        const double tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x, pb.knot_inv_h);
         yfit = yfit * kfac + tmpl * sfac;
     }
     return yfit;
@@ -1178,6 +1178,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
             hsp(pr->spline_coef, pr->spline_coef + (size_t)NF * (pr->n_knots - 1) * 4);
         for (int k = 1; k < pr->n_knots; ++k)
             if (!(hkn[k] > hkn[k - 1])) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "spline knots must ascend"));
+        const double h = (hkn.back() - hkn.front()) / (pr->n_knots - 1);
+        bool uniform = true;
+        for (int k = 0; k < pr->n_knots; ++k)
+            uniform = uniform && std::fabs(hkn[k] - (hkn.front() + k * h)) <= 1e-9 * h;
+        dp.knot_inv_h = uniform ? 1. / h : 0.;
         UP(hk, dk); UP(hs, ds); UP(hd, ddt); UP(hkn, dkn); UP(hsp, dspl);
     }
     if (pr->priors) {

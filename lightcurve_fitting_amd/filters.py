@@ -89,7 +89,7 @@ def gauss_rule(x, w, m):
 COMPRESSION_TOL = 2e-14
 #: lowest temperatures [kK] down to which the two compressed levels must hold (see PackedTables)
 COOL_TMIN = 1.0
-HOT_TMIN = 6.0
+HOT_TMIN = 8.0
 _T_GRID = np.geomspace(0.2, 2e4, 101)
 
 
@@ -356,7 +356,8 @@ class PackedTables:
         self.cutoff_freq = cutoff_freq
         # Gauss-compressed companions, two levels (empty slice + t_min = inf where a level gains nothing):
         #   "cool": the shortest rule good down to COOL_TMIN (1 kK) -- cold photospheres rarely need the full table;
-        #   "hot":  a still shorter one good down to HOT_TMIN (6 kK) at most -- where most of a fit's points are.
+        #   "hot":  a still shorter one (8, 12 or 16 nodes) good down to HOT_TMIN (8 kK) at most -- where most of a
+        #           fit's points are.
         # A level is kept only if it saves at least one quad of samples against the next longer table.
         def quads(n):
             return (n + 3) // 4
@@ -364,12 +365,12 @@ class PackedTables:
         levels = {'c': ([], [], [0], []), 'h': ([], [], [0], [])}
         for i in range(len(self.filters)):
             a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
-            cool = compress_planck_table(a, w, orders=(8, 12, 16, 24, 32), max_tmin=COOL_TMIN,
+            cool = compress_planck_table(a, w, orders=(8, 12, 16, 20, 24, 28, 32), max_tmin=COOL_TMIN,
                                          min_ratio=1.) if compress else None
             if cool is not None and quads(len(cool[0])) >= quads(len(a)):
                 cool = None
             longer = len(a) if cool is None else len(cool[0])
-            hot = compress_planck_table(a, w, orders=(8,), max_tmin=HOT_TMIN, min_ratio=1.) if compress else None
+            hot = compress_planck_table(a, w, orders=(8, 12, 16), max_tmin=HOT_TMIN, min_ratio=1.) if compress else None
             if hot is not None and (quads(len(hot[0])) >= quads(longer) or (cool is not None and hot[2] <= cool[2])):
                 hot = None
             for key, comp in (('c', cool), ('h', hot)):
