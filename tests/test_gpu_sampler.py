@@ -273,3 +273,44 @@ def test_emulated_multi_rank_run_on_one_gpu(ranks):
         chain, lp = s.get_chain()
         assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
         assert np.array_equal(s.naccepted(), ref.naccepted())
+
+
+@pytest.mark.parametrize('model_name', ['ShockCooling', 'ShockCooling4'])
+def test_chain_matches_oracle_on_a_multiband_grid(model_name):
+    """Shared epochs (thermal states per (walker, epoch) in LDS), three chunks of points in two parts, prior-excluded
+    proposals, a walker far outside the model's domain: the one-launch half-step against the oracle-driven sampler,
+    and against the two-kernel path of the same library bit for bit (separate phases through the C ABI)."""
+    rng = np.random.default_rng(77)
+    epochs = np.sort(rng.uniform(0.4, 9., 110))
+    t = np.repeat(epochs, 6)
+    names = list(np.tile(list('UBVgri'), len(epochs)))
+    bands = [O.band(n) for n in names]
+    truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    if model_name == 'ShockCooling':
+        m, om = M.ShockCooling(redshift=0.004), ('ShockCooling', O.ShockCoolingOracle(0.004))
+    else:
+        m, om = M.ShockCooling4(redshift=0.004), ('ShockCooling4', O.ShockCooling4Oracle(0.004))
+    ytrue = O.evaluate(om, t, bands, truth)
+    y, dy = ytrue * (1 + 0.05 * rng.standard_normal(len(t))), 0.05 * ytrue
+    lc = lc_dict(t, names, y, dy)
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    pb = dict(model=om, orc=None, t=t, bands=bands, y=y, dy=dy, priors=[p.descriptor() for p in priors])
+    x0 = truth * (1 + 0.05 * rng.standard_normal((40, 5)))   # R near its prior edge: some proposals are excluded
+    eng = m.engine_for(lc, priors=priors)
+    s = EnsembleSampler(40, 5, eng, seed=2024)
+    s.run_mcmc(x0, 8)
+    ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pb), x0, 8, 2024)
+    assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
+    assert 0 < s.acceptance_fraction.mean() < 1
+    from lightcurve_fitting_amd.engine import NativeSampler
+    ns = NativeSampler(eng, 40, 2024)
+    ns.set_state(x0)
+    ns.begin(0, 8, 'random', True)
+    for step in range(8):           # propose / evaluate / accept as separate launches: k_step + k_points + k_finalize
+        for half in (0, 1):
+            ns.propose(step, half)
+            ns.evaluate(0, 20)
+            ns.accept(step, half)
+    ns.check()
+    chain, lp = ns.get_chain()
+    assert np.array_equal(chain, s.get_chain()) and np.array_equal(lp, s.get_log_prob())
