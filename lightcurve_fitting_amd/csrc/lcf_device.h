@@ -161,11 +161,7 @@ __device__ inline double div_pos(double n, double d) {
     e = fma(-d, r, 1.0);
     r = fma(r, e, r);
     const double q = n * r;
-#ifdef LCF_DIV_NOCORR
-    return q;
-#else
     return fma(fma(-d, q, n), r, q);
-#endif
 }
 
 // Four samples share one division:  n1/d1 + n2/d2 = (n1 d2 + n2 d1)/(d1 d2).
@@ -173,9 +169,6 @@ __device__ inline double div_pos(double n, double d) {
 template <class TabPtr>
 __device__ inline double band_sum_main(TabPtr tab, int cnt, double spos, const ExpTab et) {
     double acc = 0.;
-#ifdef LCF_UNROLL2
-#pragma unroll 2
-#endif
     for (int k = 0; k < cnt; k += 4) {
         const double2 s0 = tab[k], s1 = tab[k + 1], s2 = tab[k + 2], s3 = tab[k + 3];
         const double d0 = exp_scaled<false>(s0.x * spos, et) - 1., d1 = exp_scaled<false>(s1.x * spos, et) - 1.;
@@ -208,10 +201,6 @@ __device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const E
     const double amax = fmax(tab[0].x, tab[cnt - 1].x);  // tables are monotonic in a_k
     const double spos = invT * kInvLn2N;
     const bool needs_safe = !(amax * invT < 170.);
-#ifdef LCF_UNIFORM_LOOP
-    const int cnt_u = __builtin_amdgcn_readfirstlane(cnt);
-    if (__builtin_amdgcn_ballot_w64(needs_safe || cnt != cnt_u) == 0) return band_sum_main(tab, cnt_u, spos, et);
-#endif
     if (__builtin_amdgcn_ballot_w64(needs_safe) == 0) return band_sum_main(tab, cnt, spos, et);
     return band_sum_safe(tab, cnt, -spos, et);
 }

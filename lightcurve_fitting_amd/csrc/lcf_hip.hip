@@ -29,11 +29,13 @@
 #include "lcf_device.h"
 #include "lcf_host.h"
 
+// Tuning knobs of the likelihood loop (measured on the 1024-walker, 3000-point fit: 2-6 chunks of prefetch and 4-6
+// waves per SIMD are within 1 % of each other; 8 waves per SIMD spill and lose 40 %).
 #ifndef LCF_KPRE
-#define LCF_KPRE 4
+#define LCF_KPRE 4   // chunks of points whose operands are fetched together
 #endif
 #ifndef LCF_WAVES
-#define LCF_WAVES 4
+#define LCF_WAVES 4  // occupancy the register allocator is asked to keep (waves per SIMD)
 #endif
 
 using namespace lcf;
