@@ -416,3 +416,28 @@ def test_model_grid_at_plotting_size():
         want = O.evaluate(orc, xfit, [O.band(f)] * len(xfit), ps.T)      # (1000, 100)
         assert relerr(got[j], want) < TOL
     print(f'model grid 6 x 1000 x 100: {dt * 1e3:.2f} ms per call (host arrays in and out)')
+
+
+def test_table_levels_switch_without_a_seam():
+    """Dense temperature sweep across the validity thresholds of the compressed tables (hot -> cool -> full): the
+    default variant against the libm evaluation of the full tables, per point, for narrow, broad and very broad bands
+    at two redshifts; plus the oracle on a coarse subset."""
+    from lightcurve_fitting_amd.filters import PackedTables
+    names = ['U', 'B', 'g', 'r', 'DLT40', 'UVW2', 'z', 'F2100W']
+    T = np.geomspace(0.25, 80., 3000)
+    R = np.full_like(T, 2.)
+    for z in (0., 0.4):
+        bb = M.Blackbody(redshift=z)
+        tabs = PackedTables(names, z=z)
+        assert np.isfinite(tabs.htmin).sum() >= 4 and np.isfinite(tabs.ctmin).sum() >= 4
+        eng, _ = bb._eval_engine(np.zeros(len(names)), names)
+        out = {}
+        for v in (2, 0):
+            eng.set_variant(v)
+            out[v] = eng.evaluate(np.column_stack([T, R]))        # (3000, nfilters)
+        ok = out[0] > 0
+        assert np.array_equal(ok, out[2] > 0)
+        assert np.max(np.abs(out[2][ok] / out[0][ok] - 1.)) < 1e-11
+        for j in (0, 2, 4):
+            want = O.synthesize_blackbody(O.band(names[j]), T[::150], R[::150], z)
+            assert relerr(out[2][::150, j], want) < TOL
