@@ -67,6 +67,7 @@ enum { LCF_N_CONSTS = 12 };
  *   SHOCK_COOLING, SHOCK_COOLING2: A, a, alpha, epsilon_1, epsilon_2, L_0, T_0, Tph_to_Tcol  (models.py:192-226)
  *   SHOCK_COOLING4:                A, a, alpha, L_br_0, T_col_br_0, t_br_0, t_tr_0           (models.py:567-577)
  *   others:                        unused
+ *   (consts[8..11] are scratch for the engine: whatever the caller puts there is overwritten)
  *
  * Band tables: filter i owns samples tab_off[i] .. tab_off[i+1]-1 of (tab_a, tab_w) with
  *   a_k = c1 nu_k (1+z)  [kK],   W_k = c2 nu'_k^3 min(1, nu_cut/nu'_k) tw_k Tnorm_k,

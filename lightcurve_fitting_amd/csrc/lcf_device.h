@@ -238,7 +238,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
                 const double lv = lq[0], lM = lq[1], lf = lq[2], lR = lq[3];
                 c[1] = (T0 * ratio / kKB) * exp(eps1 * (2. * lv - lf) + 0.25 * lR);
                 c[2] = (L0 * A) * exp(-eps2 * (lv - lf) + 2. * lv + lR);
-                c[3] = a > 0. ? alpha * (log(a / 19.5) - 0.5 * (lM - lv)) : qnan();
+                c[3] = a > 0. ? alpha * (k[11] - 0.5 * (lM - lv)) : qnan();  // k[11] = ln(a / 19.5), set at create
                 c[4] = 0.;
                 break;
             }

@@ -1145,6 +1145,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.use_ctab = have_ctab ? 1 : 0;
     e->have_ctab = have_ctab;
     std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
+    if (pr->model == LCF_MODEL_SHOCK_COOLING || pr->model == LCF_MODEL_SHOCK_COOLING3)
+        dp.consts[11] = pr->consts[1] > 0. ? std::log(pr->consts[1] / 19.5) : 0.;  // hoisted out of the half-step
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
