@@ -88,6 +88,9 @@ struct DevProblem {
     const PriorDev* priors;
 };
 
+// Doubles per walker / proposal slot in a buffer of partial chi^2 sums: one per part, then one for the log-prior.
+__device__ __host__ inline int part_stride(const DevProblem& pb) { return pb.n_parts + 1; }
+
 // a[j] for a small array that lives in the kernel arguments: a chain of scalar selects (indexing it dynamically
 // would make the compiler copy the array to scratch memory)
 __device__ inline int part_entry(const int (&a)[kMaxParts + 1], int j) {

@@ -264,7 +264,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
         pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
         tbase, fdesc, ExpTab{exptab}, out0, out1);
-    if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * pb.n_parts + part);
+    if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * part_stride(pb) + part);
 }
 
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
@@ -289,7 +289,7 @@ __global__ void k_finalize(const DevProblem pb, int n, const double* __restrict_
         return;
     }
     double s = pb.use_sigma ? 0. : pb.log_norm_const;
-    for (int k = 0; k < pb.n_parts; ++k) s += part[(size_t)w * pb.n_parts + k];
+    for (int k = 0; k < pb.n_parts; ++k) s += part[(size_t)w * part_stride(pb) + k];
     out[w] = lp - 0.5 * s;
 }
 
@@ -352,7 +352,7 @@ struct DevSampler {
     double* Q[2];       // [n_half][n_dim]     proposals
     SlotRec* rec[2];    // [n_half]
     double* newlp[2];   // [n_half]            log-posterior of the proposal (finalize kernel / all-gather)
-    double* part2[2];   // [n_half][n_parts]   chi^2 partial sums of the evaluation of half-step parity 0 / 1
+    double* part2[2];   // [n_half][n_parts + 1] per slot: chi^2 partial sums, then the log-prior; half-step parity 0 / 1
     double* chain;      // [n_steps][n_walkers][n_dim]
     double* chain_lp;   // [n_steps][n_walkers]
     long long* nacc;    // [n_walkers]
@@ -396,16 +396,6 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
     }
     for (int w = threadIdx.x; w < n_walkers; w += blockDim.x)
         perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
-}
-
-// lnL + log-prior of proposal i from its partial sums (fixed order).
-__device__ inline double finalize_one(const DevProblem& pb, const double* __restrict__ part,
-                                      const double* __restrict__ lprior, int i) {
-    const double lp = lprior[i];
-    if (lp == -INFINITY) return -INFINITY;
-    double s = pb.use_sigma ? 0. : pb.log_norm_const;
-    for (int k = 0; k < pb.n_parts; ++k) s += part[(size_t)i * pb.n_parts + k];
-    return lp - 0.5 * s;
 }
 
 // Slot of every walker in each half-step of the run (-1 where it is not active): slot_of[row][half][walker].
@@ -499,9 +489,12 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
             for (int d = 0; d < kD; ++d)
                 if (d < nd) qrow[d] = qs[d];
             if (sm.inline_finalize) {
+                // the slot's row: partial chi^2 sums, then the log-prior (of this rank's evaluation, or gathered)
+                const double* prow = sm.part2[pp] + (size_t)rslot * part_stride(pb);
                 double sum = pb.use_sigma ? 0. : pb.log_norm_const;
-                for (int k = 0; k < pb.n_parts; ++k) sum += sm.part2[pp][(size_t)rslot * pb.n_parts + k];
-                nlp = rc.lpri == -INFINITY ? -INFINITY : rc.lpri - 0.5 * sum;
+                for (int k = 0; k < pb.n_parts; ++k) sum += prow[k];
+                const double lpri = prow[pb.n_parts];
+                nlp = lpri == -INFINITY ? -INFINITY : lpri - 0.5 * sum;
             } else {
                 nlp = sm.newlp[pp][rslot];
             }
@@ -583,6 +576,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
                 for (int d = 0; d < kD; ++d)
                     if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
                 sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
+                sm.part2[cp][(size_t)i * part_stride(pb) + pb.n_parts] = lpr;  // last column of the slot's row
                 if (coef)
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
                 if (lprior) lprior[i] = lpr;
@@ -726,7 +720,7 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     if (THERM || reddened) __syncthreads();
     const double term = points_loop<VARIANT, 0, true, THERM>(pb, part, 0, sq, cs, lth, e0, ltab, fdesc, ExpTab{exptab},
                                                              nullptr, nullptr);
-    store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * pb.n_parts + part);
+    store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
 }
 
 // ---- population mode: one launch covers the same half-step of MANY independent transients (blockIdx.y) --------------
@@ -822,7 +816,7 @@ struct lcf_engine {
         LCF_HIP(hipMalloc((void**)&wP, c * dp.n_dim * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wcoef, c * kNCoef * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wlprior, c * sizeof(double)));
-        LCF_HIP(hipMalloc((void**)&wpart, c * dp.n_parts * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&wpart, c * (dp.n_parts + 1) * sizeof(double)));
         LCF_HIP(hipMalloc((void**)&wout, c * sizeof(double)));
         if (dp.use_therm) LCF_HIP(hipMalloc((void**)&wtherm, c * dp.n_epochs * sizeof(double2)));
         cap = c;
@@ -1425,7 +1419,7 @@ lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool f
     if (finalize) {
         const int bs = 128;
         hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
-                           part + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
+                           part + (size_t)lo * (e->dp.n_parts + 1), s->lprior + lo, s->ds.newlp[(s->g_next - 1) & 1] + lo);
     }
     LCF_HIP(hipGetLastError());
     return LCF_OK;
@@ -1485,7 +1479,7 @@ lcf_status launch_finalize(lcf_sampler* s, int lo, int hi, hipStream_t st) {
     lcf_engine* e = s->e;
     const int par = (int)((s->g_next - 1) & 1), bs = 128;
     hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
-                       s->ds.part2[par] + (size_t)lo * e->dp.n_parts, s->lprior + lo, s->ds.newlp[par] + lo);
+                       s->ds.part2[par] + (size_t)lo * (e->dp.n_parts + 1), s->lprior + lo, s->ds.newlp[par] + lo);
     LCF_HIP(hipGetLastError());
     return LCF_OK;
 }
@@ -1532,7 +1526,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
         AL(ds.Q[b], nh * nd); AL(ds.rec[b], nh); AL(ds.newlp[b], nh);
     }
     AL(s->coef, nh * kNCoef); AL(s->lprior, nh);
-    for (int b = 0; b < 2; ++b) AL(ds.part2[b], nh * e->dp.n_parts);
+    for (int b = 0; b < 2; ++b) AL(ds.part2[b], nh * (e->dp.n_parts + 1));
     if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
     LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
@@ -1789,8 +1783,8 @@ void lcf_comm_destroy(lcf_comm* c) {
     delete c;
 }
 
-// Whole sharded run enqueued natively: per half-step  k_step (replicated commit + proposals, thermal states of the
-// shard) -> k_points + k_finalize on the shard -> in-place ncclAllGather of the new log-posteriors.  No host
+// Whole sharded run enqueued natively: per half-step  k_fused (replicated commit + proposals; thermal states and
+// likelihood of the shard) -> in-place ncclAllGather of the shard's rows of partial sums.  No host
 // round-trip and no Python between half-steps; every rank must call it with the same arguments.
 lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_step, int64_t n_steps,
                                    int32_t split_mode, const int32_t* perm, int32_t store_chain) {
@@ -1800,12 +1794,21 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     hipStream_t st = s->e->stream;
     const int width = nh / c->n_ranks, lo = c->rank * width, hi = lo + width;
-    s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
+    // What travels is each slot's ROW (partial chi^2 sums + log-prior, n_parts + 1 doubles): the accept tests of the
+    // next launch add them up themselves, exactly as on one GPU, so no finalize launch sits in front of the collective.
+    s->ds.inline_finalize = 1;
+    const size_t stride = (size_t)s->e->dp.n_parts + 1;
     LCF_HIP(hipEventRecord(s->ev0, st));
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
-        if (lcf_status r = launch_half_step_sharded(s, lo, hi, st)) return r;
-        double* buf = s->ds.newlp[(s->g_next - 1) & 1];
-        if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo, buf, (size_t)width, /*ncclDouble*/ 8, c->comm, st),
+        if (fused_eligible(s) && hi > lo) {
+            if (lcf_status r = launch_fused(s, lo, hi, st)) return r;
+        } else {
+            if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
+            if (lcf_status r = launch_eval(s, lo, hi, s->e->dp.use_therm != 0, false, st)) return r;
+        }
+        double* buf = s->ds.part2[(s->g_next - 1) & 1];
+        if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo * stride, buf, (size_t)width * stride, /*ncclDouble*/ 8,
+                                                       c->comm, st),
                                       "ncclAllGather"))
             return r;
     }
