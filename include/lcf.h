@@ -223,7 +223,8 @@ lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t
                            lcf_comm** out);
 void lcf_comm_destroy(lcf_comm* c);
 /* The whole run of lcf_sampler_run, sharded: this rank evaluates proposals [rank*w, (rank+1)*w) of each half-step
- * (w = n_walkers / 2 / n_ranks) and one in-place ncclAllGather per half-step makes the ranks agree; enqueued on the
+ * (w = n_walkers / 2 / n_ranks) and one in-place ncclAllGather per half-step (each proposal's partial chi^2 sums and
+ * log-prior, which every rank then adds up in the same order) makes the ranks agree; enqueued on the
  * engine's stream without host synchronisation between half-steps.  Collective: same arguments on every rank. */
 lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_step, int64_t n_steps,
                                    int32_t split_mode, const int32_t* perm, int32_t store_chain);
