@@ -209,6 +209,12 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
 lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi, void* stream);
 /* Device pointer to newlp[n_walkers/2] (float64) for the collective. */
 void* lcf_sampler_newlp_ptr(lcf_sampler* s);
+/* The same half-step without the finalize launch: what the collective then carries is each proposal's ROW --
+ * its partial chi^2 sums followed by its log-prior, *row_doubles float64 -- and the accept tests of the next launch add
+ * a row up themselves (the protocol of lcf_sampler_run_sharded).  Use one protocol throughout a run.
+ * lcf_sampler_rows_ptr: device pointer to rows[n_walkers/2][*row_doubles] of the half-step drawn last. */
+lcf_status lcf_sampler_half_step_rows(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi, void* stream);
+void* lcf_sampler_rows_ptr(lcf_sampler* s, int32_t* row_doubles);
 lcf_status lcf_sampler_check(lcf_sampler* s); /* syncs; returns LCF_ERR_NAN_LOGPROB if a NaN was seen */
 
 /* ---- native multi-GPU run: RCCL bound at run time -------------------------------------------------------------- */

@@ -1494,6 +1494,13 @@ lcf_status launch_half_step_sharded(lcf_sampler* s, int lo, int hi, hipStream_t 
     return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st);  // launch_next computed the thermal states
 }
 
+// The same without the finalize launch: the shard's rows (partial sums + log-prior) are the result.
+lcf_status launch_half_step_rows(lcf_sampler* s, int lo, int hi, hipStream_t st) {
+    if (fused_eligible(s) && hi > lo) return launch_fused(s, lo, hi, st);
+    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
+    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, false, st);
+}
+
 lcf_status flush_pending(lcf_sampler* s, hipStream_t st) {
     if (!s->pending) return LCF_OK;
     return launch_next(s, false, false, 0, 0, st);
@@ -1700,6 +1707,24 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
 }
 void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
 
+lcf_status lcf_sampler_half_step_rows(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi,
+                                      void* stream) {
+    if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad step/half");
+    if (lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
+    const long long g = s->g_run0 + 2 * (step - s->run_first) + half;
+    if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
+    hipStream_t st = stream ? (hipStream_t)stream : s->e->stream;
+    s->ds.inline_finalize = 1;  // accept tests add up the gathered rows
+    return launch_half_step_rows(s, lo, hi, st);
+}
+
+void* lcf_sampler_rows_ptr(lcf_sampler* s, int32_t* row_doubles) {
+    if (!s) return nullptr;
+    if (row_doubles) *row_doubles = s->e->dp.n_parts + 1;
+    return s->ds.part2[(s->g_next - 1) & 1];
+}
+
 lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     LCF_HIP(hipSetDevice(s->e->device));
@@ -1800,12 +1825,7 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     const size_t stride = (size_t)s->e->dp.n_parts + 1;
     LCF_HIP(hipEventRecord(s->ev0, st));
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
-        if (fused_eligible(s) && hi > lo) {
-            if (lcf_status r = launch_fused(s, lo, hi, st)) return r;
-        } else {
-            if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-            if (lcf_status r = launch_eval(s, lo, hi, s->e->dp.use_therm != 0, false, st)) return r;
-        }
+        if (lcf_status r = launch_half_step_rows(s, lo, hi, st)) return r;
         double* buf = s->ds.part2[(s->g_next - 1) & 1];
         if (lcf_status r = rccl_check(g_rccl.AllGather(buf + lo * stride, buf, (size_t)width * stride, /*ncclDouble*/ 8,
                                                        c->comm, st),

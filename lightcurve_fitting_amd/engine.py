@@ -98,6 +98,8 @@ SIGNATURES = [
     ('lcf_sampler_accept', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
+    ('lcf_sampler_half_step_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ('lcf_sampler_rows_ptr', C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
     ('lcf_comm_probe', C.c_int, [C.c_char_p]),
     ('lcf_comm_unique_id', C.c_int, [C.c_char_p, C.c_void_p]),
@@ -375,6 +377,15 @@ class NativeSampler:
 
     def newlp_ptr(self):
         return self._lib.lcf_sampler_newlp_ptr(self._h)
+
+    def half_step_rows(self, step, half, lo, hi, stream=0):
+        _check(self._lib.lcf_sampler_half_step_rows(self._h, int(step), int(half), int(lo), int(hi),
+                                                    C.c_void_p(stream)))
+
+    def rows_ptr(self):
+        """(device pointer, doubles per row) of the per-proposal rows of the half-step drawn last."""
+        n = C.c_int32()
+        return self._lib.lcf_sampler_rows_ptr(self._h, C.byref(n)), int(n.value)
 
     def check(self):
         _check(self._lib.lcf_sampler_check(self._h))

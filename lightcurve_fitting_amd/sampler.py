@@ -44,9 +44,12 @@ class NativeBackend:
     """Backend over ``lcf_sampler``: device buffers live in the native library; the collective sees them as torch
     tensors through ``__cuda_array_interface__`` (no copy)."""
 
-    def __init__(self, native_sampler):
+    def __init__(self, native_sampler, rows=False):
         self.ns = native_sampler
         self.n_half = native_sampler.nwalkers // 2
+        #: what the collective carries per proposal: its row of partial chi^2 sums + log-prior (no finalize launch;
+        #: the protocol of the native ``lcf_sampler_run_sharded``), or its finished log-posterior
+        self.rows = bool(rows)
         self._newlp = {}
         self._side = None
 
@@ -78,28 +81,37 @@ class NativeBackend:
         self.ns.evaluate(lo, hi, self.stream())
 
     def half_step(self, step, half, lo, hi):
-        self.ns.half_step(step, half, lo, hi, self.stream())
+        if self.rows:
+            self.ns.half_step_rows(step, half, lo, hi, self.stream())
+        else:
+            self.ns.half_step(step, half, lo, hi, self.stream())
 
     def accept(self, step, half):
         self.ns.accept(step, half, self.stream())
 
     def newlp(self):
-        """float64 torch tensor aliasing the native ``newlp[n_half]`` buffer of the half-step drawn last (the native
-        side double-buffers it, so there are two aliases)."""
-        ptr = self.ns.newlp_ptr()
+        """float64 torch tensor aliasing the native buffer the collective works on, for the half-step drawn last:
+        ``rows[n_half][row]`` or ``newlp[n_half]`` (first axis = proposal slot either way; the native side
+        double-buffers it, so there are two aliases)."""
+        if self.rows:
+            ptr, row = self.ns.rows_ptr()
+            shape = (self.n_half, row)
+        else:
+            ptr, shape = self.ns.newlp_ptr(), (self.n_half,)
         if ptr not in self._newlp:
             import torch
-            n = self.n_half
 
             class _Alias:
-                __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False), 'version': 2,
+                __cuda_array_interface__ = {'shape': shape, 'typestr': '<f8', 'data': (ptr, False), 'version': 2,
                                             'strides': None}
             self._newlp[ptr] = torch.as_tensor(_Alias(), device=f'cuda:{self.ns.engine.device}')
         return self._newlp[ptr]
 
     def empty(self, n):
+        """Staging buffer for ``n`` proposal slots, shaped like :meth:`newlp`."""
         import torch
-        return torch.empty(n, dtype=torch.float64, device=f'cuda:{self.ns.engine.device}')
+        shape = (n, self.ns.rows_ptr()[1]) if self.rows else (n,)
+        return torch.empty(shape, dtype=torch.float64, device=f'cuda:{self.ns.engine.device}')
 
     def finish(self):
         self.ns.check()
@@ -349,7 +361,7 @@ class EnsembleSampler:
             if self._distributed() and self._native_comm() is not None:
                 self._native.run_sharded(self._comm, self._steps_done, nsteps, split, store)
             elif self._distributed():
-                ShardedStretchDriver(NativeBackend(self._native), self._group,
+                ShardedStretchDriver(NativeBackend(self._native, rows=True), self._group,
                                      force_collective=self._force_sharded).run(self._steps_done, nsteps, split, store)
             elif asynchronous:
                 self._native.run_async(self._steps_done, nsteps, split, store)

@@ -231,12 +231,14 @@ def test_odd_ensemble_sizes_match_oracle(nwalkers):
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
 
 
+@pytest.mark.parametrize('protocol', ['rows', 'lp'])
 @pytest.mark.parametrize('ranks', [2, 4])
-def test_emulated_multi_rank_run_on_one_gpu(ranks):
+def test_emulated_multi_rank_run_on_one_gpu(ranks, protocol):
     """Every kernel path of a multi-GPU run except RCCL itself: `ranks` samplers play the ranks of one ensemble on
-    one device (same seed, each evaluating only its shard through lcf_sampler_half_step, with light proposals for
-    the other shards), the all-gather is emulated by device-to-device copies between their newlp buffers.  Every
-    emulated rank must end with the chain of the fused single-GPU run, bit for bit."""
+    one device (same seed, each evaluating only its shard, with light proposals for the other shards), the
+    all-gather is emulated by device-to-device copies between their buffers -- of each proposal's row of partial sums
+    and log-prior ('rows': the protocol of the native lcf_sampler_run_sharded, no finalize launch) or of the finished
+    log-posteriors ('lp').  Every emulated rank must end with the chain of the fused single-GPU run, bit for bit."""
     import torch
     from lightcurve_fitting_amd.engine import NativeSampler
     from lightcurve_fitting_amd.sampler import NativeBackend, shard_bounds
@@ -246,7 +248,7 @@ def test_emulated_multi_rank_run_on_one_gpu(ranks):
     ref.set_state(x0)
     ref.run(0, nsteps, 'random', True)
     samplers = [NativeSampler(eng, 48, seed) for _ in range(ranks)]
-    backs = [NativeBackend(s) for s in samplers]
+    backs = [NativeBackend(s, rows=protocol == 'rows') for s in samplers]
     for s in samplers:
         s.set_state(x0)
         s.begin(0, nsteps, 'random', True)
@@ -257,9 +259,10 @@ def test_emulated_multi_rank_run_on_one_gpu(ranks):
         assert st != 0
         for step in range(nsteps):
             for half in (0, 1):
-                for r, s in enumerate(samplers):
-                    s.half_step(step, half, *bounds[r], st)
+                for r, b in enumerate(backs):
+                    b.half_step(step, half, *bounds[r])
                 views = [b.newlp() for b in backs]      # current parity's buffers
+                assert views[0].shape == ((nh, 2) if protocol == 'rows' else (nh,))  # 40 points: one part
                 for r, (lo, hi) in enumerate(bounds):   # "all-gather": rank r's shard reaches every other rank
                     for q in range(ranks):
                         if q != r and hi > lo:

@@ -2,7 +2,7 @@
 
 `ranks` samplers play the ranks of one sharded ensemble (BASELINE configs[1] shape, 1024 walkers per rank) on one
 GPU, exactly as tests/test_gpu_sampler.py::test_emulated_multi_rank_run_on_one_gpu does: same seed, every rank
-evaluates only its shard through lcf_sampler_half_step, the all-gather is device-to-device copies.  Everything a
+evaluates only its shard through lcf_sampler_half_step_rows, the all-gather is device-to-device copies.  Everything a
 rank launches per half-step except RCCL itself is therefore timed; run it under
 `rocprofv3 --kernel-trace --stats --output-format csv` for the per-kernel split.
 
@@ -30,7 +30,7 @@ def main():
     nh = nw // 2
     x0 = bench.initial_walkers(nw)
     samplers = [NativeSampler(eng, nw, 1234) for _ in range(ranks)]
-    backs = [NativeBackend(s) for s in samplers]
+    backs = [NativeBackend(s, rows=True) for s in samplers]  # rows of partial sums travel, as in the native run
     bounds = [shard_bounds(nh, ranks, r)[:2] for r in range(ranks)]
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -44,8 +44,8 @@ def main():
             t0 = time.perf_counter()
             for step in range(first, first + n):
                 for half in (0, 1):
-                    for r, s in enumerate(samplers):
-                        s.half_step(step, half, *bounds[r], st)
+                    for r, b in enumerate(backs):
+                        b.half_step(step, half, *bounds[r])
                     views = [b.newlp() for b in backs]
                     for r, (lo, hi) in enumerate(bounds):
                         for q in range(ranks):
