@@ -194,6 +194,9 @@ lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);
 /* Device time of the last lcf_sampler_run in milliseconds (HIP events on the sampler's stream). */
 double lcf_sampler_last_run_ms(const lcf_sampler* s);
+/* 1 if half-steps of this sampler run as one launch (k_fused: everything a workgroup needs fits in LDS), 0 if as
+ * proposal + likelihood launches.  Same chain either way. */
+int32_t lcf_sampler_one_launch(const lcf_sampler* s);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
  * log-probabilities (RCCL) between phase 2 and phase 3.  All enqueue on `stream` without host sync.

@@ -1706,6 +1706,7 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
     return LCF_OK;
 }
 void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
+int32_t lcf_sampler_one_launch(const lcf_sampler* s) { return s && fused_eligible(s) ? 1 : 0; }
 
 lcf_status lcf_sampler_half_step_rows(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi,
                                       void* stream) {

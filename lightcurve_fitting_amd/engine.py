@@ -98,6 +98,7 @@ SIGNATURES = [
     ('lcf_sampler_accept', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
+    ('lcf_sampler_one_launch', C.c_int32, [C.c_void_p]),
     ('lcf_sampler_half_step_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_rows_ptr', C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
@@ -377,6 +378,11 @@ class NativeSampler:
 
     def newlp_ptr(self):
         return self._lib.lcf_sampler_newlp_ptr(self._h)
+
+    @property
+    def one_launch(self):
+        """True if a half-step of this sampler is a single kernel launch (see ``lcf_sampler_one_launch``)."""
+        return bool(self._lib.lcf_sampler_one_launch(self._h))
 
     def half_step_rows(self, step, half, lo, hi, stream=0):
         _check(self._lib.lcf_sampler_half_step_rows(self._h, int(step), int(half), int(lo), int(hi),

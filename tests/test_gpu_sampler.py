@@ -317,3 +317,41 @@ def test_chain_matches_oracle_on_a_multiband_grid(model_name):
     ns.check()
     chain, lp = ns.get_chain()
     assert np.array_equal(chain, s.get_chain()) and np.array_equal(lp, s.get_log_prob())
+
+
+def test_long_light_curve_takes_the_two_kernel_path():
+    """186 000 points in 31 000 epochs: 8 parts of ~3900 epochs each do not fit the LDS budget of the one-launch
+    half-step, so the run falls back to k_step + k_points (same chain as the separate phases, bit for bit); the
+    likelihoods of the final ensemble against the oracle."""
+    from lightcurve_fitting_amd.engine import NativeSampler
+    rng = np.random.default_rng(99)
+    epochs = np.sort(rng.uniform(0.4, 30., 31000))
+    t = np.repeat(epochs, 6)
+    names = list(np.tile(list('UBVgri'), len(epochs)))
+    bands = [O.band(n) for n in names]
+    truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    om = ('ShockCooling', O.ShockCoolingOracle(0.))
+    ytrue = O.evaluate(om, t, bands, truth)
+    y, dy = ytrue * (1 + 0.05 * rng.standard_normal(len(t))), 0.05 * ytrue
+    m = M.ShockCooling(redshift=0.)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    eng = m.engine_for(lc_dict(t, names, y, dy), priors=priors)
+    x0 = truth * (1 + 0.002 * rng.standard_normal((16, 5)))
+    a = NativeSampler(eng, 16, 5)
+    assert not a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
+    a.set_state(x0)
+    a.run(0, 3, 'random', True)
+    b = NativeSampler(eng, 16, 5)
+    b.set_state(x0)
+    b.begin(0, 3, 'random', True)
+    for step in range(3):
+        for half in (0, 1):
+            b.propose(step, half)
+            b.evaluate(0, 8)
+            b.accept(step, half)
+    b.check()
+    assert np.array_equal(a.get_chain()[0], b.get_chain()[0]) and np.array_equal(a.get_chain()[1], b.get_chain()[1])
+    x, lp = a.get_state()
+    pri = [p.descriptor() for p in priors]
+    want = [O.log_posterior(om, t, bands, y, dy, pri, xi) for xi in x[:2]]
+    assert relerr(lp[:2], want) < 1e-10
