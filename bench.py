@@ -337,7 +337,8 @@ def main():
     ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population', 'companion'],
                     help="'mcmc' (default) = the headline configs[1] line; 'sed' = configs[3] extra line")
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=2000,
+                    help='ensemble steps in the timed region (BASELINE configs[1] runs 2000)')
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--full-tables-reference', action='store_true',
