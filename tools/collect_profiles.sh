@@ -32,5 +32,5 @@ print(variant, json.dumps(res))
 PY
 done
 for f in $OUT/pmc_k_fused_v*.json; do cp $f $R/profiles/${TAG}_$(basename $f); done
-python3 $R/bench.py --steps 1000 --warmup 20 --full-tables-reference > $OUT/bench_unprofiled.json 2> /dev/null
+python3 $R/bench.py --steps 1000 --warmup 20 --full-tables-reference > $OUT/bench_unprofiled.json 2> /dev/null  # -> profiles/<tag>_bench_line_full_tables.json
 cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
