@@ -1,0 +1,94 @@
+"""Property tests (hypothesis) of the host-side logic: sharding, RNG streams, splines, photometric conversions,
+the extinction law and the band-table packer.  CPU only."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+from scipy.interpolate import CubicSpline
+
+from lightcurve_fitting_amd import extinction as X, filters as F, rng
+from lightcurve_fitting_amd.lightcurve import flux2mag, mag2flux
+from lightcurve_fitting_amd.sampler import partition, shard_bounds
+from lightcurve_fitting_amd.spline import natural_coefficients, not_a_knot_coefficients
+from oracle import lcf_oracle as O
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(0, 5000), st.integers(1, 64))
+def test_shards_tile_the_half_ensemble(n_half, world):
+    covered = []
+    width = None
+    for r in range(world):
+        lo, hi, w = shard_bounds(n_half, world, r)
+        width = w if width is None else width
+        assert w == width and 0 <= lo <= hi <= n_half and hi - lo <= w
+        covered += list(range(lo, hi))
+        assert list(partition(n_half, world, r)) == list(range(lo, hi))
+    assert covered == list(range(n_half))            # disjoint, ordered, complete
+    assert width * world >= n_half                     # the padded all-gather buffer holds every shard
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2 ** 63 - 1), st.integers(0, 10 ** 6), st.sampled_from([2, 4, 10, 64, 130, 1024]))
+def test_split_permutations_match_the_oracle_stream(seed, step, nwalkers):
+    perm = rng.split_permutations(seed, step, 2, nwalkers)
+    for k in range(2):
+        assert sorted(perm[k]) == list(range(nwalkers))
+        assert np.array_equal(perm[k], O.split_permutation(seed, step + k, nwalkers))
+    keys = rng.split_keys(seed, step, nwalkers)
+    assert len(set(keys.tolist())) == nwalkers and np.array_equal(keys & 0x3fff, np.arange(nwalkers))
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.floats(0.05, 3.), min_size=4, max_size=12), st.integers(0, 2 ** 31))
+def test_spline_coefficients_match_scipy(steps, seed):
+    x = np.cumsum(steps)
+    y = np.random.default_rng(seed).standard_normal(len(x))
+    for mine, bc in ((natural_coefficients, 'natural'), (not_a_knot_coefficients, 'not-a-knot')):
+        c = mine(x, y)
+        ref = CubicSpline(x, y, bc_type=bc).c.T
+        scale = np.abs(ref).max(axis=0) + 1e-300
+        assert np.all(np.abs(c - ref) <= 1e-9 * scale + 1e-11)
+        dx = np.diff(x)   # the pieces interpolate both end knots
+        end = ((c[:, 0] * dx + c[:, 1]) * dx + c[:, 2]) * dx + c[:, 3]
+        assert np.allclose(end, y[1:], rtol=0, atol=1e-9 * (1 + np.abs(y).max()))
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.floats(-25., 30.), st.floats(0.001, 1.), st.floats(-30., 30.))
+def test_magnitude_flux_round_trip(mag, dmag, zp):
+    fl, dfl = mag2flux(np.array([mag]), np.array([dmag]), zp)
+    m, dm = flux2mag(fl, dfl, zp)
+    assert abs(m[0] - mag) < 1e-9 and abs(dm[0] - dmag) < 1e-12
+    fo, dfo = O.mag2flux(np.array([mag]), np.array([dmag]), zp)
+    assert np.allclose([fl[0], dfl[0]], [fo[0], dfo[0]], rtol=1e-14)
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.floats(1000., 40000.), st.floats(2.0, 6.0), st.floats(0., 3.))
+def test_extinction_law_properties(wave, r_v, a_v):
+    a = X.fitzpatrick99(np.array([wave]), a_v, r_v)[0]
+    assert abs(a - O.fitzpatrick99(np.array([wave]), a_v, r_v)[0]) <= 1e-12 * (1 + abs(a))
+    assert a >= 0. and abs(a - a_v * X.fitzpatrick99(np.array([wave]), 1., r_v)[0]) <= 1e-12 * (1 + a)  # linear in A_V
+    bluer = X.fitzpatrick99(np.array([wave * 0.98]), a_v, r_v)[0]
+    if wave > 2400.:  # redward of the 2175 A bump the curve falls monotonically with wavelength
+        assert bluer >= a - 1e-12
+    e = X.a_lambda_per_ebv(np.array([wave]), r_v)[0]
+    assert abs(e * (a_v / r_v) - a) <= 1e-12 * (1 + a)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.lists(st.sampled_from([f.name for f in F.all_filters if f.filename]), min_size=1, max_size=5, unique=True),
+       st.floats(0., 1.5), st.floats(1.5, 60.))
+def test_packed_tables_every_level_gives_the_same_band_sum(names, z, T):
+    tabs = F.PackedTables(names, z=z)
+    for i, n in enumerate(names):
+        a, w = tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]]
+        with np.errstate(over='ignore'):
+            full = np.sum(w / np.expm1(a / T))
+        want = O.synthesize_blackbody(O.band(n), T, 1., z)
+        assert abs(full - want) <= 1e-12 * abs(want)
+        for oo, aa, ww, tt in ((tabs.coff, tabs.ca, tabs.cw, tabs.ctmin), (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin)):
+            if T >= tt[i]:
+                ca, cw = aa[oo[i]:oo[i + 1]], ww[oo[i]:oo[i + 1]]
+                with np.errstate(over='ignore'):
+                    comp = np.sum(cw / np.expm1(ca / T))
+                assert abs(comp - full) <= 4e-14 * abs(full)
