@@ -73,9 +73,10 @@ def committed_pmc(variant):
         # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; the SQ counters cover
         # SQ_WAVES of the launched waves (512 proposals x 2 workgroups x 4 waves)
         simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 2 * 4))
-        return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+        return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES'], \
+            c['SQ_INSTS_VALU'] * (512 * 2 * 4) / c['SQ_WAVES']
     except Exception:
-        return None, None, None
+        return None, None, None, None
 
 
 def fused_kernel_ms(engine, x0, reps=100):
@@ -101,11 +102,17 @@ def roofline_entry(engine, x0, shard, variant):
     evals_per_s = shard / (kern_ms * 1e-3)
     achieved = evals_per_s * ALG_INSTR / 1e12
     hbm_gbs = evals_per_s * ALG_BYTES / 1e9
-    traffic, valu_util, valu_per_wave = committed_pmc(variant)
+    traffic, valu_util, valu_per_wave, valu_per_launch = committed_pmc(variant)
+    # vector-ALU instructions the kernel REALLY executes (PMC count per launch, 64 lanes each) over the live kernel time
+    real = None if valu_per_launch is None else 64. * valu_per_launch / (kern_ms * 1e-3) / 1e12
     return {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR, 'unit': 'Tinstr/s',
             'frac': achieved / PEAK_FP64_TINSTR, 'traffic': traffic,
             'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
             'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
+            'executed': None if real is None else {'achieved': real, 'peak': PEAK_FP64_TINSTR, 'unit': 'Tinstr/s',
+                                                   'frac': real / PEAK_FP64_TINSTR,
+                                                   'note': 'vector-ALU lane-instructions actually issued (all types), '
+                                                           'PMC count per launch / live kernel time'},
             'kernel': 'k_fused<5,1,true> (a whole half-step: commit + proposal + thermal states + likelihood)',
             'band_sum_variant': variant, 'kernel_ms': kern_ms, 'walkers_per_launch': shard,
             'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
