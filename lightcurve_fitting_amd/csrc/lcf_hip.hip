@@ -4,15 +4,18 @@
 //   photometry  t[N], y[N], dy[N], 1/dy[N], int32 pt_filt[N], pt_orig[N], pt_epoch[N]; per filter a FiltDesc
 //               -- points ordered by (part, filter), a part being a contiguous range of observation epochs;
 //               distinct observation times epoch_t[n_epochs]
-//   band tables tab[] = per filter [full | Gauss-compressed] interleaved (a_k, W_k) pairs, each padded to quads
-//   walkers     P[n][n_dim] row-major; derived coefficients coef[n][8]; thermal states therm[n][n_epochs] (1/T, R^2);
-//               partial chi^2 sums part[n][n_parts]
+//   band tables tab[] = per filter [full | cool | hot] interleaved (a_k, W_k) pairs (the last two Gauss-compressed),
+//               each padded to quads
+//   walkers     P[n][n_dim] row-major; rows part[n][n_parts + 1] = partial chi^2 sums + log-prior; on the two-kernel
+//               paths also derived coefficients coef[n][8] and thermal states therm[n][n_epochs] (1/T, R^2), which
+//               the one-launch half-step (k_fused) keeps in LDS
 // Work decomposition (k_points / k_fused): workgroup = (walker w, part j) walks the points of part j in chunks of
 // 256; lane = one data point.  The exp table and all band tables are staged in LDS once per
 // workgroup; lanes of a wave read the same LDS address (broadcast) because neighbouring points share a filter.
 // Reductions are wave shuffles + a fixed-order LDS sum: no float atomics anywhere, results are bitwise reproducible
-// run to run and independent of the GPU count.  The sampler (k_step, k_draws, k_make_perm), the multi-transient
-// launches (k_*_multi) and the RCCL-driven sharded run live further down; the SED engine is in lcf_sed.hip.
+// run to run and independent of the GPU count.  The sampler (k_fused = a whole half-step in one launch; k_step,
+// k_draws, k_make_perm), the multi-transient launches (k_*_multi) and the RCCL-driven sharded run live further down;
+// the SED engine is in lcf_sed.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
