@@ -71,9 +71,11 @@ __global__ void k_prepare(const DevProblem pb, int n, const double* __restrict__
 // (inv_tmin2 <= inv_tmin; 0 = none).  The shortest valid table is used.
 template <class TabPtr>
 struct TabSel {
-    TabPtr base;
+    TabPtr base;                // LDS copy of the first n_lds samples of the table array (or the array itself)
     long long full, cool, hot;  // offset | count << 32 of each table (count 0: the level does not exist)
     double inv_tmin, inv_tmin2;
+    const double2* gbase = nullptr;  // the whole array in global memory, when `base` holds only part of it
+    int n_lds = 0x7fffffff;
 };
 
 __device__ __forceinline__ long long tab_slice(int off, int cnt) {
@@ -85,8 +87,14 @@ __device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use
     long long sel = ts.full;
     sel = (use_ctab && invT <= ts.inv_tmin) ? ts.cool : sel;
     sel = (use_ctab && invT <= ts.inv_tmin2) ? ts.hot : sel;
-    const TabPtr tab = ts.base + (int)sel;
-    const int cnt = (int)(sel >> 32);
+    const int off = (int)sel, cnt = (int)(sel >> 32);
+    // a wave with a point whose table is not staged (colder than every compressed level, long tables) reads global
+    // memory for all its points: same values
+    if (__builtin_amdgcn_ballot_w64(off >= ts.n_lds) != 0) {
+        const double2* tab = ts.gbase + off;
+        return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
+    }
+    const TabPtr tab = ts.base + off;
     return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
 }
 
@@ -143,17 +151,17 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
         for (int k = t; k < kExpTabSize; k += nt) exptab[k] = pb.exp2tab[k];
     if (LDS_TAB) {
         // filter descriptors (48 B = 3 double2 each) behind the tables
-        double2* lfd = ltab + pb.n_tab;
+        double2* lfd = ltab + pb.n_lds_tab;
         const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
         for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
         if (pb.model == kShockCooling3) {
-            for (int k = t; k < pb.n_tab; k += nt) {
+            for (int k = t; k < pb.n_lds_tab; k += nt) {
                 double2 aw = pb.tab[k];
                 aw.y *= exp2(-ebv * pb.tab_ext[k]);
                 ltab[k] = aw;
             }
         } else {
-            for (int k = t; k < pb.n_tab; k += nt) ltab[k] = pb.tab[k];
+            for (int k = t; k < pb.n_lds_tab; k += nt) ltab[k] = pb.tab[k];
         }
     }
 }
@@ -195,7 +203,8 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
             const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt[u];
             const double2 d0 = fd[0], d1 = fd[1], d2 = fd[2];
             const TabSel<const double2*> ts{tbase, __double_as_longlong(d0.x), __double_as_longlong(d0.y),
-                                            __double_as_longlong(d1.x), d2.x, d2.y};
+                                            __double_as_longlong(d1.x), d2.x, d2.y, pb.tab,
+                                            LDS_TAB ? pb.n_lds_tab : 0x7fffffff};
             double invT, pref, Tk = 0.;
             if (THERM && MODE != 2) {
                 invT = th[u].x;
@@ -263,7 +272,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     __syncthreads();
 
     const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
-    const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_tab) : pb.f_desc;
+    const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab) : pb.f_desc;
     const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
         pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
         tbase, fdesc, ExpTab{exptab}, out0, out1);
@@ -682,8 +691,8 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
-    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_tab);
-    double* sc = reinterpret_cast<double*>(ltab + pb.n_tab + 3 * pb.n_filters);
+    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
+    double* sc = reinterpret_cast<double*>(ltab + pb.n_lds_tab + 3 * pb.n_filters);
     double* sq = sc + kNCoef + 2;
     double2* lth = reinterpret_cast<double2*>(sc + kFusedScratch);
     const int tid = threadIdx.x;
@@ -1049,8 +1058,10 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         slot[1] = (int)htab.size() - slot[0];
         return true;
     };
+    // device table = [compressed levels of every filter | full tables of every filter]: when everything does not fit
+    // in LDS the (short) compressed part still does, and only points colder than its validity read global memory
     for (int f = 0; f < NF; ++f) {
-        bool ok = append(pr->tab_a, pr->tab_w, pr->tab_off[f], pr->tab_off[f + 1], &pfull[2 * f]);
+        bool ok = true;
         if (ok && have_ctab && pr->ctab_off[f + 1] > pr->ctab_off[f]) {
             ok = append(pr->ctab_a, pr->ctab_w, pr->ctab_off[f], pr->ctab_off[f + 1], &pcomp[2 * f]);
             ptmin[f] = pr->ctab_tmin[f];
@@ -1066,6 +1077,10 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
             return bail(fail(LCF_ERR_INVALID_ARGUMENT,
                              "band tables need finite a_k > 0, finite W_k, t_min >= 0 (hot level: t_min >= the cool one's)"));
     }
+    const int n_compressed = (int)htab.size();
+    for (int f = 0; f < NF; ++f)
+        if (!append(pr->tab_a, pr->tab_w, pr->tab_off[f], pr->tab_off[f + 1], &pfull[2 * f]))
+            return bail(fail(LCF_ERR_INVALID_ARGUMENT, "band tables need finite a_k > 0 and finite W_k"));
     for (int i = 0; i < N; ++i) {
         const int o = order[i], f = pr->filt_idx[o];
         ht[i] = pr->t[o];
@@ -1133,8 +1148,12 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.sigma_abs = pr->sigma_type == LCF_SIGMA_ABSOLUTE;
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
-    dp.tab_in_lds = (int)htab.size() <= kLdsTabMax && NF <= kLdsFiltMax;
-    if (reddened && !dp.tab_in_lds)
+    // LDS holds the first n_lds_tab samples of the table array: all of it, or the compressed levels only
+    dp.n_lds_tab = NF > kLdsFiltMax ? 0
+                   : (int)htab.size() <= kLdsTabMax ? (int)htab.size()
+                   : (n_compressed > 0 && n_compressed <= kLdsTabMax) ? n_compressed : 0;
+    dp.tab_in_lds = dp.n_lds_tab > 0;
+    if (reddened && dp.n_lds_tab != (int)htab.size())  // reddened weights are made while staging the FULL tables
         return bail(fail(LCF_ERR_UNSUPPORTED, "ShockCooling3: the band tables must fit in LDS"));
     dp.n_epochs = (int)epochs.size();
     dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
@@ -1148,7 +1167,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
     e->lds_bytes = (kExpTabSize + 8) * sizeof(double) +
-                   (dp.tab_in_lds ? htab.size() * sizeof(double2) + NF * sizeof(FiltDesc) : 0);
+                   (dp.tab_in_lds ? dp.n_lds_tab * sizeof(double2) + NF * sizeof(FiltDesc) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
     int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;

@@ -441,3 +441,49 @@ def test_table_levels_switch_without_a_seam():
         for j in (0, 2, 4):
             want = O.synthesize_blackbody(O.band(names[j]), T[::150], R[::150], z)
             assert relerr(out[2][::150, j], want) < TOL
+
+
+def test_long_tables_stage_only_their_compressed_levels():
+    """UVOT + optical + 2MASS + TESS + DECam: 4300 table samples do not fit in LDS, their compressed levels (< 200) do;
+    points colder than every level read the full table from global memory.  Likelihoods against the oracle for every
+    variant, a walker cold enough to need the full tables included, and the one-launch sampler path stays available."""
+    from lightcurve_fitting_amd.engine import NativeSampler
+    from lightcurve_fitting_amd.filters import PackedTables
+    rng = np.random.default_rng(3)
+    filts = ['UVW2', 'UVW1', 'U', 'B', 'V', 'g', 'r', 'i', 'J', 'H', 'K', 'TESS', 'z-DECam']
+    tabs = PackedTables(filts, z=0.01)
+    assert tabs.off[-1] > 3700 > tabs.coff[-1] + tabs.hoff[-1]
+    epochs = np.sort(rng.uniform(0.5, 12., 60))
+    t = np.repeat(epochs, len(filts))
+    names = list(np.tile(filts, len(epochs)))
+    m = M.ShockCooling(redshift=0.01)
+    truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    orc = ('ShockCooling', O.ShockCoolingOracle(0.01))
+    bands = [O.band(n) for n in names]
+    ytrue = O.evaluate(orc, t, bands, truth)
+    y, dy = ytrue * (1 + 0.05 * rng.standard_normal(len(t))), 0.05 * ytrue
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.4)]
+    eng = m.engine_for(lc_dict(t, names, y, dy), priors=priors)
+    P = truth * (1 + 0.1 * rng.standard_normal((32, 5)))
+    P[0, 3], P[1, 3] = 0.01, 1e-5      # cold: below the validity of the compressed levels of the bluer bands
+    Tcold = O.ShockCoolingOracle(0.01).temperature_radius(t, *P[1])[0]
+    assert np.nanmin(Tcold) < 0.5
+    want = O.log_likelihood(orc, t, bands, y, dy, P.T)
+    for v in (2, 1, 0):
+        eng.set_variant(v)
+        assert relerr(eng.log_likelihood(P), want) < TOL
+    eng.set_variant(2)
+    a = NativeSampler(eng, 32, 4)
+    assert a.one_launch
+    a.set_state(P)
+    a.run(0, 4, 'random', True)
+    b = NativeSampler(eng, 32, 4)
+    b.set_state(P)
+    b.begin(0, 4, 'random', True)
+    for step in range(4):
+        for half in (0, 1):
+            b.propose(step, half)
+            b.evaluate(0, 16)
+            b.accept(step, half)
+    b.check()
+    assert np.array_equal(a.get_chain()[0], b.get_chain()[0]) and np.array_equal(a.get_chain()[1], b.get_chain()[1])
