@@ -59,7 +59,8 @@ struct DevProblem {
     int n_dim, n_par, use_sigma, sigma_abs;
     int n_knots, has_priors, tab_in_lds, variant;
     int n_epochs, use_therm, use_ctab, n_tab;
-    int n_lds_tab, pad5;  // samples of `tab` staged in LDS: all, or the compressed levels only (they come first)
+    int n_lds_tab;    // samples of `tab` staged in LDS: all, or the compressed levels only (they come first)
+    int redden_slow;  // ShockCooling3 whose tables do not fit in LDS: reddening applied per sample from global memory
     int n_parts, cpb, pad2, pad3;  // workgroups per walker ("parts"), most point chunks in one part
     int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs ...
     int part_ep0[kMaxParts + 1];    // ... namely the epochs [part_ep0[j], part_ep0[j+1]) (when use_therm)

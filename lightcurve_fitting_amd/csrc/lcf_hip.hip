@@ -104,7 +104,15 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
                                      const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
                                      const ExpTab et, double invT, double pref) {
     double S = 0.;
-    if (invT > 0.) {
+    if (invT > 0. && pb.redden_slow) {
+        // ShockCooling3 through tables too long for LDS: the walker's reddening is applied sample by sample to the
+        // full table in global memory (libm; a fall-back, not a fast path)
+        const int off = (int)ts.full, cnt = (int)(ts.full >> 32);
+        for (int k = 0; k < cnt; ++k) {
+            const double2 aw = pb.tab[off + k];
+            S += aw.y * exp2(-c[6] * pb.tab_ext[off + k]) / expm1(aw.x * invT);
+        }
+    } else if (invT > 0.) {
         S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT, et);
         if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
             const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT * (1. / 0.74), et);
@@ -154,7 +162,7 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
         double2* lfd = ltab + pb.n_lds_tab;
         const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
         for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
-        if (pb.model == kShockCooling3) {
+        if (pb.model == kShockCooling3 && !pb.redden_slow) {
             for (int k = t; k < pb.n_lds_tab; k += nt) {
                 double2 aw = pb.tab[k];
                 aw.y *= exp2(-ebv * pb.tab_ext[k]);
@@ -1152,9 +1160,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_lds_tab = NF > kLdsFiltMax ? 0
                    : (int)htab.size() <= kLdsTabMax ? (int)htab.size()
                    : (n_compressed > 0 && n_compressed <= kLdsTabMax) ? n_compressed : 0;
+    // reddened weights are made while staging the FULL tables; when those do not fit nothing is staged and the
+    // reddening is applied on the fly (slow path)
+    dp.redden_slow = reddened && dp.n_lds_tab != (int)htab.size();
+    if (dp.redden_slow) dp.n_lds_tab = 0;
     dp.tab_in_lds = dp.n_lds_tab > 0;
-    if (reddened && dp.n_lds_tab != (int)htab.size())  // reddened weights are made while staging the FULL tables
-        return bail(fail(LCF_ERR_UNSUPPORTED, "ShockCooling3: the band tables must fit in LDS"));
     dp.n_epochs = (int)epochs.size();
     dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
     dp.variant = 1;

@@ -74,12 +74,7 @@ def test_shock_cooling_family_fuzz(seed):
     # packs the tables (documented deviation)
     P[:, 5] = np.abs(P[:, 5])
     lc3 = {'MJD': t, 'filter': names, 'flux': y * 1e-47, 'dflux': dy * 1e-47}
-    from lightcurve_fitting_amd.engine import LcfError
-    try:
-        eng = m3.engine_for(lc3)
-    except LcfError as exc:  # reddened models need their tables in LDS (very long JWST / UVOT tables do not fit)
-        assert exc.status == 5 and sum(F.filtdict[x].nsamples for x in set(names)) > 3000
-        return
+    eng = m3.engine_for(lc3)   # (tables too long for LDS: reddening applied on the fly, same numbers)
     eng.set_variant(min(variant, 1))
     assert relerr(eng.evaluate(P), O.evaluate(o3, t, bands, P.T).T) < 2e-11, ('ShockCooling3', z)
     want = O.log_likelihood(o3, t, bands, lc3['flux'], lc3['dflux'], P.T)
