@@ -30,7 +30,7 @@ typedef enum lcf_status {
     LCF_ERR_HIP = 2,              /* a HIP runtime call failed; see lcf_last_error() */
     LCF_ERR_NO_DEVICE = 3,        /* no usable GPU: this library has no CPU fallback */
     LCF_ERR_OUT_OF_MEMORY = 4,
-    LCF_ERR_UNSUPPORTED = 5,      /* e.g. a reddened model whose band tables do not fit in LDS   */
+    LCF_ERR_UNSUPPORTED = 5,      /* e.g. an unknown model id, or a host-supplied split in a population run */
     LCF_ERR_NAN_LOGPROB = 6,      /* sampler: a log-probability evaluated to NaN (emcee raises ValueError here) */
     LCF_ERR_STATE = 7             /* call sequence error (e.g. run before set_state) */
 } lcf_status;
