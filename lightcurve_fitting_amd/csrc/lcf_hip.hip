@@ -99,12 +99,14 @@ __device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use
 }
 
 // Everything one lane does for its data point after the thermal state (1/T, R_bb^2): band sum(s) -> template term.
-template <int VARIANT, class TabPtr>
+// STAGED: the band tables (or their compressed levels) are in LDS; the on-the-fly reddening fall-back exists only in
+// the unstaged instantiations, so that it costs the staged kernels no registers.
+template <int VARIANT, bool STAGED, class TabPtr>
 __device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
                                      const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
                                      const ExpTab et, double invT, double pref) {
     double S = 0.;
-    if (invT > 0. && pb.redden_slow) {
+    if (!STAGED && invT > 0. && pb.redden_slow) {
         // ShockCooling3 through tables too long for LDS: the walker's reddening is applied sample by sample to the
         // full table in global memory (libm; a fall-back, not a fast path)
         const int off = (int)ts.full, cnt = (int)(ts.full >> 32);
@@ -185,7 +187,9 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
     const int tid = threadIdx.x;
     double term = 0.;
     const int p0 = part_entry(pb.part_start, part), p1 = part_entry(pb.part_start, part + 1);  // this part's points
-    constexpr int kPre = LCF_KPRE;  // chunks whose operands are fetched together, before any band sum starts
+    // chunks whose operands are fetched together, before any band sum starts (fewer when the thermal state is computed
+    // per point: that code needs the registers)
+    constexpr int kPre = THERM ? LCF_KPRE : 2;
     for (int k0 = 0; k0 * kBlock < p1 - p0; k0 += kPre) {
         int idx[kPre], filt[kPre];
         double tin[kPre], yv[kPre], idy[kPre];
@@ -228,7 +232,7 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 out1[j] = sqrt(pref);
                 continue;
             }
-            const double yfit = point_model<VARIANT>(pb, c, p, tin[u], filt[u], ts, et, invT, pref);
+            const double yfit = point_model<VARIANT, LDS_TAB>(pb, c, p, tin[u], filt[u], ts, et, invT, pref);
             if (MODE == 0) {  // models.py:121-135
                 const double r = yv[u] - yfit;
                 if (pb.use_sigma) {
@@ -1494,7 +1498,9 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
         case 4: LCF_FUSED(4); break;
         case 5: LCF_FUSED(5); break;
         case 6: LCF_FUSED(6); break;
+        case 7: LCF_FUSED(7); break;
         case 8: LCF_FUSED(8); break;
+        case 9: LCF_FUSED(9); break;
         default: LCF_FUSED(0); break;
     }
 #undef LCF_FUSED

@@ -277,3 +277,28 @@ def test_fitzpatrick99_law():
     e_all = O.fitzpatrick99(O.C_NM_THZ * 10. / nu, 3.1, 3.1)
     sl = slice(tabs.off[1], tabs.off[2])
     assert relerr(np.sort(tabs.ext[sl]), np.sort(e_all[np.isin(np.round(O.C1 * nu, 9), np.round(tabs.a[sl], 9))])) < 1e-12
+
+
+def test_hot_kernels_neither_spill_nor_lose_occupancy():
+    """The compiler's resource report written by the build (csrc/liblcf_hip.resources.txt): the one-launch half-step
+    and the likelihood kernel, in the instantiations the benchmark and the fits use, must stay free of scratch memory
+    and vector-register spills at 4 waves per SIMD -- a code change that silently costs that loses 25 % (it happened)."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(E.__file__), 'csrc', 'liblcf_hip.resources.txt')
+    if not os.path.exists(path):
+        pytest.skip('no resource report next to the library (built without the Makefile)')
+    text = open(path).read()
+    blocks = {}
+    for m in re.finditer(r'Function Name: (\S+)(.*?)(?=Function Name:|\Z)', text, re.S):
+        fields = dict(re.findall(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)', m.group(2)))
+        blocks[m.group(1)] = fields
+    # k_fused<ND = 4..9, fast band sum, thermal states shared per epoch or computed per point>,
+    # k_points<fast band sum, likelihood mode, tables staged, both thermal modes>
+    hot = [k for k in blocks if re.search(r'k_fusedILi[4-9]ELi1ELb[01]E', k) or
+           re.search(r'k_pointsILi1ELi0ELb1ELb[01]E', k)]
+    assert len(hot) == 14, sorted(blocks)[:5]
+    for k in hot:
+        f = blocks[k]
+        assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0, (k, f)
+        assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
