@@ -1,0 +1,21 @@
+"""Fit speed on a light curve without shared epochs (every point at its own time: thermal state per point)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import bench
+from lightcurve_fitting_amd import models as M
+from lightcurve_fitting_amd.engine import NativeSampler
+rng = np.random.default_rng(5)
+t = np.sort(rng.uniform(0.5, 10., 3000))
+names = list(rng.choice(bench.BANDS, 3000))
+m = M.ShockCooling(redshift=0.)
+ytrue = m(t, names, *bench.TRUTH)
+lc = {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * rng.standard_normal(3000)), 'dlum': 0.05 * ytrue}
+pri = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+eng = m.engine_for(lc, priors=pri)
+for nw in (100, 1024):
+    s = NativeSampler(eng, nw, 3)
+    s.set_state(bench.initial_walkers(nw))
+    s.run(0, 20, 'random', False); s.run(20, 500, 'random', False)
+    ms = s.last_run_ms() / 500
+    print(f'ragged 3000 points, {nw} walkers: {ms * 1e3:.1f} us per step, {nw / ms * 1e3 / 1e6:.2f}e6 walker-steps/s, one launch: {s.one_launch}')
