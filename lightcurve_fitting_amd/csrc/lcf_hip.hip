@@ -994,9 +994,13 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     // workgroup needs the thermal states of those epochs only. ----
     // distinct observation times (exact equality): the thermal state depends on (walker, time) only
     const bool all_finite_t = std::all_of(pr->t, pr->t + N, [](double v) { return std::isfinite(v); });
+    // (with a non-finite time there is no strict weak order to sort by: every point is then its own epoch, in the
+    // caller's order, and nothing below compares times)
     std::vector<double> epochs(pr->t, pr->t + N);
-    std::sort(epochs.begin(), epochs.end());
-    epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
+    if (all_finite_t) {
+        std::sort(epochs.begin(), epochs.end());
+        epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
+    }
     const int n_chunks_all = std::max(1, (N + kBlock - 1) / kBlock);
     // workgroups per walker: every one repeats the prologue (table staging; in the fused sampler kernel also the
     // serial part of the half-step), so few of them -- two up to 16 chunks, then one per 8 chunks (measured on the
@@ -1110,8 +1114,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         med = (N & 1) ? sorted_dy[N / 2] : 0.5 * (sorted_dy[N / 2 - 1] + sorted_dy[N / 2]);
     }
     std::vector<int> hepoch(N);
-    for (int i = 0; i < N; ++i)
-        hepoch[i] = (int)(std::lower_bound(epochs.begin(), epochs.end(), ht[i]) - epochs.begin());
+    for (int i = 0; i < N; ++i) hepoch[i] = ep_of[horig[i]];
     int n_chunks = 0, cpb = 1;  // chunks of kBlock points: total over the parts, and the most in one part
     for (int j = 0; j < n_parts; ++j) {
         const int c = (part_start[j + 1] - part_start[j] + kBlock - 1) / kBlock;

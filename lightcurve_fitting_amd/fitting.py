@@ -31,6 +31,46 @@ def make_log_posterior(lc, model, priors=None, use_sigma=False, sigma_type='rela
     return log_posterior
 
 
+def _prepare_photometry(lc, model):
+    """The column the model is fitted to, derived from the magnitudes when ``lc`` knows how (fitting.py:68-72)."""
+    if not hasattr(lc, 'calcAbsMag'):
+        return                                           # plain column stores (dict of arrays) carry it already
+    for method in {'flux': ('calcFlux',), 'lum': ('calcAbsMag', 'calcLum')}.get(model.output_quantity, ()):
+        getattr(lc, method)()
+
+
+def _bound_vector(values, ndim, fill, *, deprecated=False, name=None, fallback=None):
+    """One of the four length-``ndim`` keyword vectors of ``lightcurve_mcmc`` as a float array.
+
+    ``None`` -> ``fallback`` if given, else ``ndim`` copies of ``fill``; a wrong length raises with the reference's
+    message (the deprecation text for ``p_min`` / ``p_max``, which also warn when they are used at all)."""
+    if values is None:
+        return np.full(ndim, fill) if fallback is None else fallback
+    if len(values) != ndim:
+        raise Exception(PRIOR_WARNING if deprecated else '{} must have length {:d}'.format(name, ndim))
+    if deprecated:
+        warnings.warn(PRIOR_WARNING)
+    return np.asarray(values, dtype=float).copy()
+
+
+def _resolve_priors(priors, p_min, p_max, ndim):
+    if priors is None:
+        return [UniformPrior(lo, hi) for lo, hi in zip(p_min, p_max)]
+    if len(priors) != ndim:
+        raise Exception('priors must have length {:d}'.format(ndim))
+    return priors
+
+
+def _check_start_box(names, priors, p_lo, p_up):
+    """The box the walkers start in must lie inside the priors' support (fitting.py:113-119)."""
+    for k, (param, prior) in enumerate(zip(names, priors)):
+        for label, guess, limit_name, limit, outside in (('p_lo', p_lo[k], 'p_min', prior.p_min, p_lo[k] < prior.p_min),
+                                                         ('p_up', p_up[k], 'p_max', prior.p_max, p_up[k] > prior.p_max)):
+            if outside:
+                raise Exception(f'starting guess for {param} ({label} = {guess}) is outside prior '
+                                f'({limit_name} = {limit})')
+
+
 def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p_up=None,
                     nwalkers=100, nsteps=1000, nsteps_burnin=1000, model_kwargs=None,
                     show=False, save_plot_as='', save_sampler_as='', use_sigma=False, sigma_type='relative',
@@ -45,58 +85,20 @@ def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p
     """
     if model_kwargs is not None:
         raise Exception(MODEL_KWARGS_WARNING)
-
-    if hasattr(lc, 'calcAbsMag'):
-        if model.output_quantity == 'flux':
-            lc.calcFlux()
-        elif model.output_quantity == 'lum':
-            lc.calcAbsMag()
-            lc.calcLum()
-
-    if use_sigma and model.input_names[-1] != '\\sigma':
+    _prepare_photometry(lc, model)
+    if use_sigma and model.input_names[-1] != '\\sigma':   # the intrinsic-scatter parameter joins the model's own
         model.input_names.append('\\sigma')
         model.units.append('')
-
     ndim = model.nparams
 
-    if p_min is None:
-        p_min = np.tile(-np.inf, ndim)
-    elif len(p_min) == ndim:
-        p_min = np.array(p_min, float)
-        warnings.warn(PRIOR_WARNING)
-    else:
-        raise Exception(PRIOR_WARNING)
-
-    if p_max is None:
-        p_max = np.tile(np.inf, ndim)
-    elif len(p_max) == ndim:
-        p_max = np.array(p_max, float)
-        warnings.warn(PRIOR_WARNING)
-    else:
-        raise Exception(PRIOR_WARNING)
-
-    if p_lo is None:
-        p_lo = p_min
-    elif len(p_lo) == ndim:
-        p_lo = np.array(p_lo, float)
-    else:
-        raise Exception('p_lo must have length {:d}'.format(ndim))
-
-    if p_up is not None and len(p_up) == ndim:
-        p_up = np.array(p_up, float)
-    else:
+    p_min = _bound_vector(p_min, ndim, -np.inf, deprecated=True)
+    p_max = _bound_vector(p_max, ndim, np.inf, deprecated=True)
+    p_lo = _bound_vector(p_lo, ndim, None, name='p_lo', fallback=p_min)
+    if p_up is None:
         raise Exception('p_up must have length {:d}'.format(ndim))
-
-    if priors is None:
-        priors = [UniformPrior(p0, p1) for p0, p1 in zip(p_min, p_max)]
-    elif len(priors) != ndim:
-        raise Exception('priors must have length {:d}'.format(ndim))
-
-    for param, prior, p0, p1 in zip(model.input_names, priors, p_lo, p_up):
-        if p0 < prior.p_min:
-            raise Exception(f'starting guess for {param} (p_lo = {p0}) is outside prior (p_min = {prior.p_min})')
-        if p1 > prior.p_max:
-            raise Exception(f'starting guess for {param} (p_up = {p1}) is outside prior (p_max = {prior.p_max})')
+    p_up = _bound_vector(p_up, ndim, None, name='p_up')
+    priors = _resolve_priors(priors, p_min, p_max, ndim)
+    _check_start_box(model.input_names, priors, p_lo, p_up)
 
     # log_posterior of fitting.py:121-128 lives on the device: priors are baked into the engine
     engine = model.engine_for(lc, use_sigma=use_sigma, sigma_type=sigma_type, priors=priors)
@@ -104,16 +106,13 @@ def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p
         seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
     sampler = EnsembleSampler(nwalkers, ndim, engine, seed=seed)
 
-    starting_guesses = np.random.rand(nwalkers, ndim) * (p_up - p_lo) + p_lo
-    pos, _, _ = sampler.run_mcmc(starting_guesses, nsteps_burnin)
-
+    start = p_lo + (p_up - p_lo) * np.random.rand(nwalkers, ndim)      # uniform in the starting box
+    burned_in = sampler.run_mcmc(start, nsteps_burnin)
     if show or save_plot_as:
         warnings.warn('chain plots are not produced by the MI355X engine; plot sampler.chain with the reference tools')
-
-    sampler.reset()
-    sampler.run_mcmc(pos, nsteps, skip_initial_state_check=True)
+    sampler.reset()                                                    # keep only the post-burn-in chain
+    sampler.run_mcmc(burned_in.coords, nsteps, skip_initial_state_check=True)
     if save_sampler_as:
-        np.save(save_sampler_as, sampler.flatchain)
         print('saving sampler.flatchain as ' + save_sampler_as)
-
+        np.save(save_sampler_as, sampler.flatchain)
     return sampler

@@ -160,34 +160,28 @@ class LC:
         self.columns['filter'] = filters
 
     # --- selection (lightcurve.py:87-134) ------------------------------------------------------------------------
+    #: keyword suffix -> (row test against ONE value, how the tests of a list of values combine)
+    _CRITERIA = {
+        '': (lambda column, v: _same(column, v), np.logical_or),
+        '_not': (lambda column, v: ~_same(column, v), np.logical_and),
+        '_min': (lambda column, v: column >= v, np.logical_or),
+        '_max': (lambda column, v: column <= v, np.logical_or),
+    }
+
     def where(self, **kwargs):
-        """Rows matching every criterion: ``col=value``, ``col_not=``, ``col_min=``, ``col_max=``; lists match any."""
-        use = np.ones(len(self), bool)
-        for col, val in kwargs.items():
-            if col.startswith('filter'):
-                if isinstance(val, str):
-                    val = filtdict[val]
-                elif isinstance(val, list):
-                    val = [filtdict[v] if isinstance(v, str) else v for v in val]
-            if isinstance(val, list):
-                if '_not' in col:
-                    use1 = np.ones(len(self), bool)
-                    for v in val:
-                        use1 &= self[col.replace('_not', '')] != v
-                else:
-                    use1 = np.zeros(len(self), bool)
-                    for v in val:
-                        use1 |= self[col] == v
-            elif '_min' in col:
-                use1 = self[col.replace('_min', '')] >= val
-            elif '_max' in col:
-                use1 = self[col.replace('_max', '')] <= val
-            elif '_not' in col:
-                use1 = self[col.replace('_not', '')] != val
-            else:
-                use1 = self[col] == val
-            use &= np.asarray(use1, dtype=bool)
-        return self[use]
+        """Rows matching every criterion: ``col=value``, ``col_not=``, ``col_min=``, ``col_max=``.  A list of values
+        matches any of them (``_not``: none of them); filters may be given by name."""
+        keep = np.ones(len(self), dtype=bool)
+        for key, wanted in kwargs.items():
+            suffix = next((s for s in ('_not', '_min', '_max') if s in key), '')
+            test, combine = self._CRITERIA[suffix]
+            column = self[key.replace(suffix, '') if suffix else key]
+            values = wanted if isinstance(wanted, list) else [wanted]
+            if key.startswith('filter'):
+                values = [filtdict[v] if isinstance(v, str) else v for v in values]
+            hits = [np.asarray(test(column, v), dtype=bool) for v in values]
+            keep &= combine.reduce(hits) if hits else np.full(len(self), suffix == '_not')
+        return self[keep]
 
     # --- photometric conversions -------------------------------------------------------------------------------
     @property
@@ -207,44 +201,34 @@ class LC:
     def calcAbsMag(self, dm=None, extinction=None, hostext=None, ebv=None, rv=None, host_ebv=None, host_rv=None,
                    redshift=None):
         """``'absmag'`` from ``'mag'``: distance modulus and per-filter extinction coefficients, given or computed
-        from E(B-V) and R_V at each filter's effective wavelength (lightcurve.py:271-345)."""
-        if redshift is not None:
-            self.meta['redshift'] = redshift
-        elif 'redshift' not in self.meta:
-            self.meta['redshift'] = 0.
+        from E(B-V) and R_V at each filter's effective wavelength (lightcurve.py:271-345).  Arguments override what
+        ``meta`` holds; what is computed here is remembered in ``meta`` like the reference does."""
+        meta = self.meta
+        meta['redshift'] = redshift if redshift is not None else meta.get('redshift', 0.)
         if dm is not None:
-            self.meta['dm'] = dm
-        elif 'dm' not in self.meta and self.meta.get('redshift'):
-            raise NotImplementedError('no cosmology on this host: pass the distance modulus dm')
-        elif 'dm' not in self.meta:
-            self.meta['dm'] = 0.
-        if ebv is None:
-            ebv = self.meta.get('ebv')
-        if host_ebv is None:
-            host_ebv = self.meta.get('host_ebv')
-        if rv is None:
-            rv = self.meta.get('rv', 3.1)
-        if host_rv is None:
-            host_rv = self.meta.get('host_rv', 3.1)
-        with_table = [f for f in set(self['filter']) if f.wl_eff is not None]
-        if extinction is not None:
-            self.meta['extinction'] = extinction
-        elif 'extinction' not in self.meta:
-            self.meta['extinction'] = {} if ebv is None else {f.name: f.extinction(ebv, rv) for f in with_table}
-        if hostext is not None:
-            self.meta['hostext'] = hostext
-        elif 'hostext' not in self.meta:  # the reference reads the host redshift from meta['z'] here (:330)
-            self.meta['hostext'] = {} if host_ebv is None else {
-                f.name: f.extinction(host_ebv, host_rv, self.meta.get('z', 0.)) for f in with_table}
-        absmag = np.asarray(self['mag'], dtype=float) - self.meta['dm']
-        filt_col = self['filter']
-        for filtobj in set(filt_col):
-            rows = np.array([f == filtobj for f in filt_col])
-            for key in ('extinction', 'hostext'):
-                for name in filtobj.names:
-                    if name in self.meta[key]:
-                        absmag[rows] -= self.meta[key][name]
-                        break
+            meta['dm'] = dm
+        elif 'dm' not in meta:
+            if meta['redshift']:
+                raise NotImplementedError('no cosmology on this host: pass the distance modulus dm')
+            meta['dm'] = 0.
+
+        filters = set(self['filter'])
+        # (meta key, coefficients given, E(B-V), R_V, redshift of the dust); the reference reads the host's redshift
+        # from meta['z'] (lightcurve.py:330)
+        screens = (('extinction', extinction, _first(ebv, meta.get('ebv')), _first(rv, meta.get('rv'), 3.1), 0.),
+                   ('hostext', hostext, _first(host_ebv, meta.get('host_ebv')),
+                    _first(host_rv, meta.get('host_rv'), 3.1), meta.get('z', 0.)))
+        absmag = np.asarray(self['mag'], dtype=float) - meta['dm']
+        for key, given, colour_excess, r_v, z_dust in screens:
+            if given is not None:
+                meta[key] = given
+            elif key not in meta:
+                meta[key] = {} if colour_excess is None else {
+                    f.name: f.extinction(colour_excess, r_v, z_dust) for f in filters if f.wl_eff is not None}
+            for filtobj in filters:       # the first of the filter's names with a coefficient wins
+                a_lambda = next((meta[key][n] for n in filtobj.names if n in meta[key]), None)
+                if a_lambda is not None:
+                    absmag[_same(self['filter'], filtobj)] -= a_lambda
         self['absmag'] = absmag
 
     def calcLum(self, nondetSigmas=None):
@@ -254,6 +238,21 @@ class LC:
         nondet = self['nondet'] if 'nondet' in self else None
         self['lum'], self['dlum'] = mag2flux(self['absmag'], np.asarray(self['dmag'], dtype=float), self.zp + 90.19,
                                              nondet, self.nondetSigmas)
+
+
+def _same(column, value):
+    """Element-wise ``column == value`` as a boolean array (object columns compare entry by entry; ``None`` by
+    identity, as the reference's ``where`` does)."""
+    if value is None:
+        return np.array([v is None for v in column], dtype=bool)
+    if getattr(column, 'dtype', None) == object:
+        return np.array([v == value for v in column], dtype=bool)
+    return np.asarray(column == value, dtype=bool)
+
+
+def _first(*candidates):
+    """The first argument that is not None (None if there is none)."""
+    return next((c for c in candidates if c is not None), None)
 
 
 def _has_objects(value):

@@ -106,6 +106,25 @@ def _photometry(lc, quantity):
     return t, filts, y, dy
 
 
+class _BoundEngine:
+    """An engine together with the photometry it was created from (host copies, for the content check)."""
+    __slots__ = ('engine', 'mode', 't', 'filters', 'y', 'dy')
+
+    def __init__(self, engine, mode, t, filters, y, dy):
+        self.engine, self.mode = engine, mode
+        self.t, self.y, self.dy = t.copy(), y.copy(), dy.copy()
+        self.filters = filters.copy()
+
+    def holds(self, t, filters, y, dy):
+        """True if the engine's photometry equals these columns (NaNs compare equal to NaNs)."""
+        if t.shape != self.t.shape:
+            return False
+        for mine, theirs in ((self.y, y), (self.dy, dy), (self.t, t)):
+            if mine.shape != theirs.shape or not np.array_equal(mine, theirs, equal_nan=True):
+                return False
+        return filters.shape == self.filters.shape and bool(np.all(filters == self.filters))
+
+
 def _index_filters(filts):
     """Distinct filters (first-seen order) and the per-point index into them."""
     uniq = list(dict.fromkeys(filts))
@@ -125,6 +144,8 @@ class Model:
     model_id = None
     #: E(B-V) is a model parameter: band-table weights are reddened per walker (full tables only)
     reddened = False
+    #: photometry-bound engines one model keeps (each holds a copy of a light curve on the device)
+    max_bound_engines = 8
 
     def __init__(self, lc=None, redshift=0.):
         if redshift:
@@ -136,7 +157,8 @@ class Model:
         # instance-level copies: lightcurve_mcmc(use_sigma=True) appends '\\sigma' (fitting.py:74-76)
         self.input_names = list(type(self).input_names)
         self.units = list(type(self).units)
-        self._engines = {}
+        self._engines = {}   # evaluation engines (model grids), keyed by the (times, filters) they were built for
+        self._bound = []     # engines bound to photometry, most recently used first (see engine_for)
         self.device = 0
 
     @property
@@ -186,17 +208,29 @@ class Model:
                            tab_ext=tabs.ext)
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):
-        """Engine bound to ``lc`` (cached per light-curve object, sigma mode and prior set)."""
-        key = (id(lc), bool(use_sigma), sigma_type, None if priors is None else tuple(p.descriptor() for p in priors))
-        eng = self._engines.get(key)
-        if eng is None:
-            if sigma_type not in ('relative', 'absolute'):
-                raise Exception('sigma_type must either be "relative" or "absolute"')
-            t, filts, y, dy = _photometry(lc, self.output_quantity)
-            eng = self.make_engine(t, filts, y, dy, use_sigma, sigma_type, priors)
-            if len(self._engines) > 8:
-                self._engines.pop(next(iter(self._engines))).close()
-            self._engines[key] = eng
+        """Engine bound to the photometry ``lc`` holds NOW (sigma mode and prior set as given).
+
+        The reference reads the light-curve columns on every ``log_likelihood`` call (models.py:116-119); an engine
+        copies them to the device once.  Engines are therefore cached by the CONTENT of the four columns, compared on
+        every call: editing ``lc['lum']`` in place, or a new light-curve object at a recycled address, gets a new
+        engine.  An engine that leaves the cache is only dropped, never destroyed here -- samplers and closures that
+        were handed it keep it alive."""
+        if sigma_type not in ('relative', 'absolute'):
+            raise Exception('sigma_type must either be "relative" or "absolute"')
+        t = np.asarray(_column(lc, 'MJD'), dtype=np.float64)
+        y = np.asarray(_column(lc, self.output_quantity), dtype=np.float64)
+        dy = np.asarray(_column(lc, 'd' + self.output_quantity), dtype=np.float64)
+        filt_col = np.asarray(_column(lc, 'filter'), dtype=object)
+        mode = (bool(use_sigma), sigma_type, None if priors is None else tuple(p.descriptor() for p in priors))
+        for k, bound in enumerate(self._bound):
+            if bound.mode == mode and bound.holds(t, filt_col, y, dy):
+                if k:  # most recently used first
+                    self._bound.insert(0, self._bound.pop(k))
+                return bound.engine
+        filts = [as_filter(f) for f in filt_col]
+        eng = self.make_engine(t, filts, y, dy, use_sigma, sigma_type, priors)
+        self._bound.insert(0, _BoundEngine(eng, mode, t, filt_col, y, dy))
+        del self._bound[self.max_bound_engines:]
         return eng
 
     # --- the reference's public surface --------------------------------------------------------------------------
@@ -226,9 +260,7 @@ class Model:
         eng = self._engines.get(key)
         if eng is None:
             eng = self.make_engine(t, fl, np.zeros(len(t)), np.ones(len(t)))
-            for k in [k for k in self._engines if k[0] == 'eval']:
-                self._engines.pop(k).close()
-            self._engines[key] = eng
+            self._engines = {key: eng}  # one evaluation grid at a time; the old engine dies with its last reference
         return eng, shape
 
     def evaluate(self, t_in, f, *params):
