@@ -79,15 +79,15 @@ def committed_pmc(variant):
         return None, None, None, None
 
 
-def fused_kernel_ms(engine, x0, reps=100):
+def fused_kernel_ms(engine, x0, reps=1000):
     """Average duration of the dominant kernel, k_fused (one launch = one half-step of a 1024-walker ensemble =
     512 proposals: commit + draw + thermal states + likelihood), from HIP events on the engine's stream around
     `reps` steps = 2*reps back-to-back launches (plus one trailing 5-us commit launch, i.e. < 0.03 us per launch)."""
     from lightcurve_fitting_amd.engine import NativeSampler
     s = NativeSampler(engine, WALKERS_PER_GPU, SEED + 7)
     s.set_state(x0[:WALKERS_PER_GPU])
-    s.run(0, 10, 'random', False)
-    s.run(10, reps, 'random', False)
+    s.run(0, 50, 'random', False)
+    s.run(50, reps, 'random', False)
     ms = s.last_run_ms() / (2 * reps)
     s.close()
     return ms

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 4
+#define LCF_ABI_VERSION 5
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -194,9 +194,17 @@ lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);
 /* Device time of the last lcf_sampler_run in milliseconds (HIP events on the sampler's stream). */
 double lcf_sampler_last_run_ms(const lcf_sampler* s);
-/* 1 if half-steps of this sampler run as one launch (k_fused: everything a workgroup needs fits in LDS), 0 if as
+/* 1 if half-steps of this sampler run as one launch (everything a workgroup needs fits in LDS), 0 if as
  * proposal + likelihood launches.  Same chain either way. */
 int32_t lcf_sampler_one_launch(const lcf_sampler* s);
+/* Which kernels a single-GPU run (lcf_sampler_run / _run_async) may use for a half-step.  All of them produce the
+ * same chain bit for bit; the choice exists for tests and measurements.
+ *   AUTO:   one workgroup per proposal that also accepts / rejects (k_solo) where a proposal's parts fit one
+ *           workgroup, else one workgroup per (proposal, part) (k_fused), else proposal + likelihood launches
+ *   FUSED:  never k_solo        PHASES: always proposal + likelihood launches
+ * Returns in *used (optional) what a run would use now: 2 = k_solo, 1 = k_fused, 0 = separate launches. */
+enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2 };
+lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
  * log-probabilities (RCCL) between phase 2 and phase 3.  All enqueue on `stream` without host sync.
@@ -231,6 +239,12 @@ lcf_status lcf_comm_unique_id(const char* rccl_path, lcf_comm_id* out);
 lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t n_ranks, int32_t rank, int32_t device,
                            lcf_comm** out);
 void lcf_comm_destroy(lcf_comm* c);
+/* Number of ranks as the communicator itself reports it (ncclCommCount), and this rank's index (ncclCommUserRank). */
+lcf_status lcf_comm_count(const lcf_comm* c, int32_t* n_ranks, int32_t* rank);
+/* Measurement hook for bench.py: average time [ms] of ONE in-place all-gather as lcf_sampler_run_sharded issues it per
+ * half-step for sampler s (its rows, float64), `reps` of them back to back on the engine's stream between two HIP
+ * events.  Collective: every rank calls it with the same arguments. */
+lcf_status lcf_comm_time_allgather(lcf_comm* c, lcf_sampler* s, int32_t reps, double* avg_ms);
 /* The whole run of lcf_sampler_run, sharded: this rank evaluates proposals [rank*w, (rank+1)*w) of each half-step
  * (w = n_walkers / 2 / n_ranks) and one in-place ncclAllGather per half-step (each proposal's partial chi^2 sums and
  * log-prior, which every rank then adds up in the same order) makes the ranks agree; enqueued on the

@@ -132,8 +132,8 @@ def spectrum_mcmc_population(epochs, priors=None, z=0., nwalkers=10, burnin_step
     ndim = 3 if use_sigma else 2
     if priors is None:
         priors = [UniformPrior(*T_range), LogUniformPrior(*R_range)] + ([UniformPrior(0., 10.)] if use_sigma else [])
-    if nwalkers < 2 * ndim or nwalkers % 2:
-        raise ValueError('nwalkers must be even and at least 2 * ndim')
+    if nwalkers < 2 * ndim:
+        raise ValueError('nwalkers must be at least 2 * ndim')
     problems, x0 = [], {}
     rng = np.random.default_rng(seed)
     for k, (filts, y, dy) in enumerate(epochs):

@@ -102,10 +102,10 @@ __device__ inline int part_entry(const int (&a)[kMaxParts + 1], int j) {
     return v;
 }
 
+__device__ inline double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
 // power() of the reference: base > 0 ? base**exp : 0, also for NaN bases.  models.py:42-48
 __device__ inline double pw(double base, double e) { return base > 0. ? pow(base, e) : 0.; }
-
-__device__ inline double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Band sum  S(T) = sum_k W_k / (exp(a_k / T) - 1)           filters.py:308-310 + models.py:1127-1128
@@ -367,13 +367,19 @@ __device__ inline double spline_eval(const double* __restrict__ knots, int nk, c
     return fma(fma(fma(q[0], dx, q[1]), dx, q[2]), dx, q[3]);
 }
 
-// Temperature [kK] and the factor `pref` such that  L_nu = pref * S(T)  (pref = R_bb^2), for one data point.
-// Sets T = 0 (and pref = 0 or NaN) where the reference's power() zeroing makes the band integral vanish.
+// Temperature [kK], its reciprocal, and the factor `pref` such that  L_nu = pref * S(T)  (pref = R_bb^2), for one
+// data point.  Sets T = 1/T = 0 (and pref = 0 or NaN) where the reference's power() zeroing makes the band integral
+// vanish.
+__device__ inline double inv_temperature(double Tk) {  // 1 / Tk for 0 < Tk < kTmax
+    return 1. / Tk;
+}
+
 __device__ inline void thermal_state(const DevProblem& pb, const double* __restrict__ c, double t_in, double& T,
-                                     double& pref) {
+                                     double& invT, double& pref) {
     const double* k = pb.consts;
     const double t = t_in - c[0];
     T = 0.;
+    invT = 0.;
     pref = 0.;
     switch (pb.model) {
         case kShockCooling:
@@ -388,8 +394,9 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
                 if (!(L >= 0.)) {
                     pref = qnan();
                 } else if (Tk > 0. && Tk < kTmax) {
-                    const double i2 = 1. / (Tk * Tk);
+                    const double i1 = inv_temperature(Tk), i2 = i1 * i1;
                     T = Tk;
+                    invT = i1;
                     pref = kC3sq * L * i2 * i2;  // R_bb^2 = c3^2 L T^-4      models.py:268
                 }  // else: T <= 0 or NaN -> power(T, -2) = 0 -> R_bb = 0
             } else if (t < 0. && c[4] != 0.) {
@@ -414,8 +421,9 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
             if (!(L >= 0.)) {
                 pref = qnan();
             } else if (Tk > 0. && Tk < kTmax) {
-                const double i2 = 1. / (Tk * Tk);
+                const double i1 = inv_temperature(Tk), i2 = i1 * i1;
                 T = Tk;
+                invT = i1;
                 pref = kC3sq * L * i2 * i2;
             }
             break;
@@ -431,6 +439,7 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
                     const double Tk = c[1] * exp(-74. / 144. * lt);
                     if (Tk > 0. && Tk < kTmax) {
                         T = Tk;
+                        invT = inv_temperature(Tk);
                         pref = c[2] * exp(14. / 9. * lt);  // R^2 = (2.7 (Mv t^7)^(1/9))^2
                     }
                 }
@@ -440,6 +449,7 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
         case kBlackbody:
             if (c[1] > 0. && c[1] < kTmax) {
                 T = c[1];
+                invT = inv_temperature(c[1]);
                 pref = c[2];
             } else if (c[2] != c[2]) {
                 pref = qnan();

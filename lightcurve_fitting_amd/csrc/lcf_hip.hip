@@ -147,9 +147,9 @@ __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_l
     if (idx >= n_w * pb.n_epochs) return;
     const int w = w_lo + idx / pb.n_epochs, ep = idx % pb.n_epochs;
     if (skip_excluded && lprior[w] == -INFINITY) return;
-    double T, pref;
-    thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, pref);
-    therm[(size_t)w * pb.n_epochs + ep] = make_double2(T > 0. ? 1. / T : 0., pref);
+    double T, invT, pref;
+    thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, invT, pref);
+    therm[(size_t)w * pb.n_epochs + ep] = make_double2(invT, pref);
 }
 
 // Stage the exp table and ALL band tables in LDS; thread t of nt.  ShockCooling3: the walker's reddening goes into
@@ -179,17 +179,16 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
 // The points of part `part` for one walker: parameters p, coefficients c (global or LDS), thermal states
 // th[pt_epoch - e_off] when THERM.  MODE 0: returns this thread's share of chi^2;  MODE 1: y_fit -> out0[row][orig];
 // MODE 2: T, R_bb -> out0, out1.
-template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM, int KPRE_POINTWISE = 2>
 __device__ inline double points_loop(const DevProblem& pb, int part, size_t row, const double* __restrict__ p,
                                      const double* __restrict__ c, const double2* __restrict__ th_base, int e_off,
                                      const double2* tbase, const FiltDesc* fdesc, const ExpTab et,
-                                     double* __restrict__ out0, double* __restrict__ out1) {
-    const int tid = threadIdx.x;
-    double term = 0.;
+                                     double* __restrict__ out0, double* __restrict__ out1, int tid = threadIdx.x) {
+    double term = 0.;  // `tid`: this thread's index among the kBlock threads that walk the part
     const int p0 = part_entry(pb.part_start, part), p1 = part_entry(pb.part_start, part + 1);  // this part's points
     // chunks whose operands are fetched together, before any band sum starts (fewer when the thermal state is computed
     // per point: that code needs the registers)
-    constexpr int kPre = THERM ? LCF_KPRE : 2;
+    constexpr int kPre = THERM ? LCF_KPRE : KPRE_POINTWISE;
     for (int k0 = 0; k0 * kBlock < p1 - p0; k0 += kPre) {
         int idx[kPre], filt[kPre];
         double tin[kPre], yv[kPre], idy[kPre];
@@ -222,8 +221,7 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 invT = th[u].x;
                 pref = th[u].y;
             } else {
-                thermal_state(pb, c, tin[u], Tk, pref);
-                invT = Tk > 0. ? 1. / Tk : 0.;
+                thermal_state(pb, c, tin[u], Tk, invT, pref);
             }
             if (MODE == 2) {
                 // R_bb = sqrt(pref) keeps the reference's NaN/0 pattern (pref = R_bb^2)
@@ -422,7 +420,9 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
         perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
 }
 
-// Slot of every walker in each half-step of the run (-1 where it is not active): slot_of[row][half][walker].
+// Slot of every walker in each half-step of a block of steps (-1 where it is not active).  Rows of `slot_of`
+// ([1 + 2 n_steps][n_walkers]): row 0 = the half-step in front of the block (copied from the previous block, or all
+// -1 at the start of a run), row 1 + 2 k + half = half-step (k, half) of the block.
 __global__ void k_slots(int n_walkers, int n_half, const int* __restrict__ perm, long long n_steps,
                         int* __restrict__ slot_of) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,11 +431,15 @@ __global__ void k_slots(int n_walkers, int n_half, const int* __restrict__ perm,
     const int pos = (int)(idx % n_walkers);  // position in the permutation: colour 0 = first n_half entries
     const int wid = perm ? perm[idx] : pos;
     const int half = pos < n_half ? 0 : 1, slot = pos < n_half ? pos : pos - n_half;
-    slot_of[((size_t)row * 2 + half) * n_walkers + wid] = slot;
-    slot_of[((size_t)row * 2 + (1 - half)) * n_walkers + wid] = -1;
+    slot_of[((size_t)row * 2 + 1 + half) * n_walkers + wid] = slot;
+    slot_of[((size_t)row * 2 + 1 + (1 - half)) * n_walkers + wid] = -1;
 }
 
-// The state-independent half of every stretch move of a run, one thread per (step, half, slot).
+// The state-independent half of every stretch move of a block of steps, one thread per (step, half, slot).
+// n_half = ceil(n_walkers / 2) slots per half-step: colour 0 (the first n_half entries of the step's permutation)
+// moves in half 0 against the n_walkers - n_half walkers of colour 1, then colour 1 against colour 0 -- the larger
+// colour first, as emcee's red-blue split does for an odd ensemble; the slot an odd ensemble leaves empty in half 1
+// gets wid = -1.  `slot_of` null: no slot bookkeeping (the one-workgroup-per-proposal half-step does not need it).
 __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* __restrict__ slot_of,
                         long long first_step, long long n_steps, DrawRec* __restrict__ draws) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,7 +447,15 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     const int i = (int)(idx % sm.n_half), half = (int)((idx / sm.n_half) & 1);
     const long long row = idx / (2 * sm.n_half);
     const int* pr = perm ? perm + (size_t)row * sm.n_walkers : nullptr;
-    const int n_other = sm.n_walkers - sm.n_half;
+    const int n_act = half == 0 ? sm.n_half : sm.n_walkers - sm.n_half, n_other = sm.n_walkers - n_act;
+    DrawRec d;
+    if (i >= n_act) {
+        d.wid = d.pid = d.wprev = d.pprev = -1;
+        d.z = 1.;
+        d.zl = d.lnu = d.pad = 0.;
+        draws[idx] = d;
+        return;
+    }
     const int my_slot = half == 0 ? i : sm.n_half + i;  // colour 0 = first n_half entries of the permutation
     const int wid = pr ? pr[my_slot] : my_slot;
     uint32_t r[4], s2[4];
@@ -454,12 +466,11 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     int j = (int)(u01(r[2], r[3]) * (double)n_other);
     j = min(j, n_other - 1);
     const int other_slot = half == 0 ? sm.n_half + j : j;
-    DrawRec d;
     d.wid = wid;
     d.pid = pr ? pr[other_slot] : other_slot;
-    const long long hprev = row * 2 + half - 1;  // previous half-step of the run
-    d.wprev = hprev >= 0 ? slot_of[(size_t)hprev * sm.n_walkers + d.wid] : -1;
-    d.pprev = hprev >= 0 ? slot_of[(size_t)hprev * sm.n_walkers + d.pid] : -1;
+    const int* before = slot_of ? slot_of + (size_t)(row * 2 + half) * sm.n_walkers : nullptr;  // the half-step in front
+    d.wprev = before ? before[d.wid] : -1;
+    d.pprev = before ? before[d.pid] : -1;
     d.z = z;
     d.zl = (double)(sm.n_dim - 1) * log(z);
     d.lnu = log(u01(s2[0], s2[1]));
@@ -486,12 +497,13 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
     const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
     DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
     if (have_next) dr = draws[i];
+    const bool active = have_next && dr.wid >= 0;  // (an odd ensemble leaves the last slot of its second half-step empty)
     // --- roles: which accept test (if any) this lane evaluates ---
     int rw = -1, rslot = -1;
-    if (lane == 0 && have_prev && primary) {
+    if (lane == 0 && have_prev && primary && prev_wid >= 0) {
         rslot = i;
         rw = prev_wid;  // walker of slot i in the previous half-step (from its draw record)
-    } else if ((lane == 1 || lane == 2) && have_next) {
+    } else if ((lane == 1 || lane == 2) && active) {
         rw = lane == 1 ? dr.wid : dr.pid;
         rslot = have_prev ? (lane == 1 ? dr.wprev : dr.pprev) : -1;
     }
@@ -547,7 +559,14 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
             sm.chain_lp[(size_t)prev_row * sm.n_walkers + rw] = lp_cur;
         }
     }
-    if (have_next) {
+    if (have_next && !active) {  // empty slot: nothing to propose; its workgroups skip the likelihood
+        if (lane == 0) {
+            if (sc) sc[kNCoef] = -INFINITY;
+            if (primary && lprior) lprior[i] = -INFINITY;
+        }
+        return;
+    }
+    if (active) {
         double q[kMaxDim], lq[kMaxDim];
         double arg = 1.;
 #pragma unroll
@@ -658,9 +677,9 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     // a workgroup covers kBlock epochs with blockDim.x threads (64-thread workgroups when there are few epochs)
     const int ep_end = min((ec + 1) * kBlock, pb.n_epochs);
     for (int e2 = ep; e2 < ep_end; e2 += blockDim.x) {
-        double T, pref;
-        thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, pref);
-        therm[(size_t)i * pb.n_epochs + e2] = make_double2(T > 0. ? 1. / T : 0., pref);
+        double T, invT, pref;
+        thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, invT, pref);
+        therm[(size_t)i * pb.n_epochs + e2] = make_double2(invT, pref);
     }
 }
 
@@ -736,9 +755,9 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     if (THERM) {
         const int e1 = part_entry(pb.part_ep0, part + 1);
         for (int e = e0 + tid; e < e1; e += kBlock) {
-            double T, pref;
-            thermal_state(pb, cs, pb.epoch_t[e], T, pref);
-            lth[e - e0] = make_double2(T > 0. ? 1. / T : 0., pref);
+            double T, invT, pref;
+            thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
+            lth[e - e0] = make_double2(invT, pref);
         }
     }
     if (THERM || reddened) __syncthreads();
@@ -747,15 +766,210 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
 }
 
+// Diagnostic build only (-DLCF_STAMPS, tools/debug/make_stamp_build.py; never shipped): s_memtime stamps of the first 64
+// workgroups of k_solo, written by the first lane of wave `W` into a buffer nothing else reads.
+#ifdef LCF_STAMPS
+__device__ unsigned long long g_stamps[64 * 16];
+#define LCF_STAMP(W, k)                                                                                        \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) g_stamps[blockIdx.x * 16 + (k)] = t_;                  \
+    } while (0)
+#else
+#define LCF_STAMP(W, k) do {} while (0)
+#endif
+
+// ---- single-GPU fit, one workgroup per PROPOSAL: a half-step that owns its accept test ------------------------------
+// k_fused gives every (proposal, part) its own workgroup, so no workgroup knows the proposal's likelihood: the accept
+// test is re-derived by whoever needs the walker in the next launch, from per-slot records (proposal, draw, partial
+// sums) that every launch publishes and the next one loads.  Here ONE workgroup of NPARTS x 256 threads evaluates all
+// parts of its proposal -- threads [256 j, 256 j + 256) walk part j exactly as a k_fused workgroup would, same chunks,
+// same reduction tree, so the chain is bitwise the one k_fused and the two-kernel path produce -- and thread 0 then
+// accepts or rejects and commits the walker itself.  What that removes from the serial head of every half-step:
+// the second dependent round trip (slot records, proposals and partial sums of three slots), the three redundant
+// accept tests, the per-part repetition of the whole serial section, and every global store except the commit.
+// Within a launch X[wid] is read and written by the walker's own workgroup only (partners come from the
+// complementary colour, which this half-step does not move), so there is nothing to synchronise.
+constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // doubles: coefficients, log-prior, q, x
+
+template <int ND, int VARIANT, bool THERM, int NPARTS>
+__global__ __launch_bounds__(kBlock * NPARTS, LCF_WAVES)
+void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
+            const DrawRec* draws_next) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* exptab = reinterpret_cast<double*>(smem);
+    double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
+    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
+    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
+    double* sc = reinterpret_cast<double*>(ltab + pb.n_lds_tab + 3 * pb.n_filters);  // coefficients, then log-prior
+    double* sq = sc + kNCoef + 2;                                           // the proposal
+    double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
+    double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
+    constexpr int kThreads = kBlock * NPARTS;
+    constexpr int kD = ND > 0 ? ND : kMaxDim;
+    const int nd = ND > 0 ? ND : sm.n_dim;
+    const int tid = threadIdx.x, i = blockIdx.x;
+    const bool reddened = pb.model == kShockCooling3;
+    LCF_STAMP(0, 0);
+    const DrawRec dr = draws[i];     // wave-uniform
+    if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
+    LCF_STAMP(0, 1);
+    if (tid < 64) {
+        // ---- serial head, one wave: proposal -> logarithms (one parameter per lane) -> coefficients, log-prior
+        const int lane = tid;
+        PriorDev my_prior{0, 0, 0., 0., 0., 1.};
+        if (lane < pb.n_dim && pb.has_priors) my_prior = pb.priors[lane];
+        const double* xs = sm.X + (size_t)dr.wid * nd;
+        const double* cs_ = sm.X + (size_t)dr.pid * nd;
+        double x[kD], q[kMaxDim], lq[kMaxDim];
+#pragma unroll
+        for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
+        const double lp_i = sm.LP[dr.wid];
+        double arg = 1.;
+#pragma unroll
+        for (int d = 0; d < kD; ++d) {
+            x[d] = d < nd ? xs[d] : 0.;
+            const double cj = d < nd ? cs_[d] : 0.;
+            q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
+            if (lane == d && d < pb.n_par) arg = q[d];
+        }
+#ifdef LCF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        LCF_STAMP(0, 2);
+        const double lg = log(arg);
+#pragma unroll
+        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
+        LCF_STAMP(0, 3);
+        double c[kNCoef];
+        walker_coefficients(pb, q, lq, c);
+        LCF_STAMP(0, 4);
+        double lpr = 0.;
+        if (pb.has_priors) {
+            double qv = 0.;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (lane == d) qv = q[d];
+            const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
+            sc[kNCoef] = lpr;
+#pragma unroll
+            for (int d = 0; d < kD; ++d)
+                if (d < nd) {
+                    sq[d] = q[d];
+                    sx[d] = x[d];
+                }
+            sx[kMaxDim] = lp_i;
+        }
+        LCF_STAMP(0, 5);
+    } else {
+        // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
+        // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
+        // (a hint only: nothing depends on the value or on the placement).
+        if (tid == 64 && draws_next != nullptr) {
+            const volatile int* nxt = reinterpret_cast<const volatile int*>(draws_next + i);
+            (void)nxt[0];
+            (void)nxt[sizeof(DrawRec) / sizeof(int) - 1];
+        }
+        if (!reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
+        LCF_STAMP(1, 11);
+    }
+    __syncthreads();
+    LCF_STAMP(0, 6);
+    const double lpr = sc[kNCoef];
+    double term = 0.;
+    const bool excluded = lpr == -INFINITY;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
+    if (!excluded) {
+        double cs[kNCoef];
+#pragma unroll
+        for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
+        if (reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, cs[6], tid, kThreads);
+        const int part = tid / kBlock, ltid = tid % kBlock;
+        if (THERM) {
+            // thread (part, ltid) computes the epochs a k_fused workgroup of that part would: same values, all in LDS
+            const int e0 = part_entry(pb.part_ep0, part), e1 = part_entry(pb.part_ep0, part + 1);
+#pragma unroll 1
+            for (int e = e0 + ltid; e < e1; e += kBlock) {
+                double T, invT, pref;
+                thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
+                lth[e] = make_double2(invT, pref);
+            }
+        }
+        if (THERM || reddened) __syncthreads();
+        LCF_STAMP(0, 7);
+        if (part < pb.n_parts)
+            term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
+                                                           nullptr, nullptr, ltid);
+        LCF_STAMP(0, 8);
+        LCF_STAMP(1, 12);
+        const double ws = wave_sum(term);
+        if ((tid & 63) == 0) red[tid >> 6] = ws;
+    }
+    __syncthreads();
+    LCF_STAMP(0, 9);
+    if (tid != 0) return;
+    // ---- accept / reject and commit (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move)
+    double nlp = -INFINITY;
+    if (!excluded) {
+        double sum = pb.use_sigma ? 0. : pb.log_norm_const;   // fixed order: parts, each (w0 + w1) + (w2 + w3)
+        for (int k = 0; k < pb.n_parts; ++k) sum += (red[4 * k] + red[4 * k + 1]) + (red[4 * k + 2] + red[4 * k + 3]);
+        nlp = lpr - 0.5 * sum;
+    }
+    const double lp_i = sx[kMaxDim];
+    const bool ok = (dr.zl + nlp - lp_i) > dr.lnu;   // emcee: (ndim - 1) ln z + lp_new - lp_old > ln u
+    if (nlp != nlp) atomicExch(sm.err, 1);
+    if (ok) {
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) sm.X[(size_t)dr.wid * nd + d] = sq[d];
+        sm.LP[dr.wid] = nlp;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sm.nacc[dr.wid]), 1ull);  // (no return value: nothing waits)
+    }
+    if (sm.store_chain) {
+        double* crow = sm.chain + ((size_t)row * sm.n_walkers + dr.wid) * nd;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) crow[d] = ok ? sq[d] : sx[d];
+        sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = ok ? nlp : lp_i;
+    }
+    LCF_STAMP(0, 10);
+}
+
+// State of the sampler as 8-byte words into (mapped, pinned) host memory: [error flag | X | LP | n_accepted].
+__global__ void k_snapshot(const DevSampler sm, unsigned long long* __restrict__ out) {
+    const long long nx = (long long)sm.n_walkers * sm.n_dim, nw = sm.n_walkers;
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) out[0] = (unsigned long long)(unsigned int)*sm.err;
+    else if (w <= nx) out[w] = reinterpret_cast<const unsigned long long*>(sm.X)[w - 1];
+    else if (w <= nx + nw) out[w] = reinterpret_cast<const unsigned long long*>(sm.LP)[w - 1 - nx];
+    else if (w <= nx + 2 * nw) out[w] = (unsigned long long)sm.nacc[w - 1 - nx - nw];
+}
+
 // ---- population mode: one launch covers the same half-step of MANY independent transients (blockIdx.y) --------------
 struct MultiItem {
     DevProblem pb;
     DevSampler sm;
-    const DrawRec* draws;  // [n_steps][2][n_half]
+    const DrawRec* draws[2];        // the sampler's two block buffers (block b in buffer b & 1)
+    long long blk_first, blk_steps; // steps in block 0 / in every later block
     double* coef;
     double* lprior;
     double2* therm;
 };
+
+// Draw records of a transient's half-step `rel` of the run (the host keeps that block resident).
+__device__ inline const DrawRec* item_rows(const MultiItem& it, long long rel) {
+    const long long k = rel / 2;
+    const long long b = k < it.blk_first ? 0 : 1 + (k - it.blk_first) / it.blk_steps;
+    const long long k0 = b == 0 ? 0 : it.blk_first + (b - 1) * it.blk_steps;
+    return it.draws[b & 1] + (size_t)(rel - 2 * k0) * it.sm.n_half;
+}
 
 template <int ND>
 __global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restrict__ items, int have_prev,
@@ -766,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restri
     const int nec = thermal ? (it.pb.n_epochs + kBlock - 1) / kBlock : 1;
     if ((int)blockIdx.x >= nh * nec) return;
     step_body<ND>(it.pb, it.sm, blockIdx.x, have_prev, prev_row, have_next,
-              have_next ? it.draws + (size_t)rel * nh : nullptr, have_prev ? it.draws + (size_t)(rel - 1) * nh : nullptr,
+              have_next ? item_rows(it, rel) : nullptr, have_prev ? item_rows(it, rel - 1) : nullptr,
               g, 0, nh, nec, thermal, it.coef, it.lprior, it.therm);
 }
 
@@ -1373,17 +1587,43 @@ struct lcf_sampler {
     std::vector<void*> owned;
     double *coef = nullptr, *lprior = nullptr;
     double2* therm = nullptr;
-    int* d_perm = nullptr;
-    int64_t perm_rows = 0;  // rows allocated
-    DrawRec* d_draws = nullptr;
-    int64_t draw_rows = 0;
-    bool have_perm = false;
+    // The state-independent draws of a run are produced in BLOCKS of steps, two buffers (block b lives in buffer b & 1):
+    // device memory does not grow with the run, the first half-step starts after a short first block, and nothing on
+    // the host waits for the generation.  The generation kernels go on the SAME stream as the half-steps, between two
+    // of them: block b + 1 right behind the first launch of block b (the last reader of the buffer it overwrites), so
+    // stream order is all the synchronisation there is.  (Measured at 1024 walkers x 2000 steps: a low- or
+    // normal-priority side stream with events cost 3-4 % of the whole run however rarely it was used; the inline
+    // kernels cost 40 us per 256 steps.)
+    int64_t blk_first = 0, blk_steps = 0;          // steps in block 0 and in every later block
+    int64_t blk_cap = 0;                           // steps a buffer holds
+    int* d_perm[2] = {nullptr, nullptr};           // [blk_cap][n_walkers]
+    DrawRec* d_draws[2] = {nullptr, nullptr};      // [blk_cap][2][n_half]
+    int* d_slot[2] = {nullptr, nullptr};           // [1 + 2 blk_cap][n_walkers] (row 0: the half-step in front)
+    int* d_perm_host = nullptr;                    // LCF_SPLIT_HOST: the caller's permutations of the whole run
+    int64_t perm_host_rows = 0;
+    int split_mode = LCF_SPLIT_IDENTITY;
+    bool need_slots = true;                        // draw records carry the slots of the previous half-step
+    int64_t blk_generated = -1;                    // last block whose generation is enqueued
+    int64_t blk_current = -1;                      // block the half-steps are in
     int64_t run_first = 0, run_steps = 0;
+    int64_t spec_first = -1;   // >= 0: buffer 0 holds the first block of a run starting at this step (speculated)
+    int spec_mode = 0;
+    bool spec_slots = false;
     int64_t chain_cap = 0;
     bool has_state = false;
     long long g_next = 2;     // global half-step counter (never reused: see lcf_sampler_begin)
     long long g_run0 = 2;     // first half-step of the current run
     bool pending = false;     // the last proposed half-step is not committed yet
+    bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
+    int half_step_kernel = LCF_HALF_STEP_AUTO;
+    // Snapshot of (error flag, positions, log-posteriors, acceptance counts) in pinned host memory, copied behind the
+    // last launch of a run: the calls that read them back after the run wait for nothing more.
+    unsigned char* snap = nullptr;
+    bool snap_enqueued = false, snap_valid = false;
+    size_t snap_x() const { return 8; }
+    size_t snap_lp() const { return snap_x() + (size_t)ds.n_walkers * ds.n_dim * sizeof(double); }
+    size_t snap_acc() const { return snap_lp() + (size_t)ds.n_walkers * sizeof(double); }
+    size_t snap_bytes() const { return snap_acc() + (size_t)ds.n_walkers * sizeof(long long); }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.;
 
@@ -1392,14 +1632,123 @@ struct lcf_sampler {
         for (void* p : owned) hipFree(p);
         if (ds.chain) hipFree(ds.chain);
         if (ds.chain_lp) hipFree(ds.chain_lp);
-        if (d_perm) hipFree(d_perm);
-        if (d_draws) hipFree(d_draws);
+        free_blocks();
+        if (snap) hipHostFree(snap);
+        if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
+    }
+    void free_blocks() {
+        for (int b = 0; b < 2; ++b) {
+            if (d_perm[b]) hipFree(d_perm[b]);
+            if (d_draws[b]) hipFree(d_draws[b]);
+            if (d_slot[b]) hipFree(d_slot[b]);
+            d_perm[b] = nullptr;
+            d_draws[b] = nullptr;
+            d_slot[b] = nullptr;
+        }
+        blk_cap = 0;
+    }
+    // block of the run's step k (relative), and the block's first step / length
+    int64_t block_of_step(int64_t k) const { return k < blk_first ? 0 : 1 + (k - blk_first) / blk_steps; }
+    int64_t block_start(int64_t b) const { return b == 0 ? 0 : blk_first + (b - 1) * blk_steps; }
+    int64_t block_len(int64_t b) const {
+        return std::min(run_steps, block_start(b) + (b == 0 ? blk_first : blk_steps)) - block_start(b);
+    }
+    // draw records of the run's half-step `rel` (its block must be resident)
+    const DrawRec* rows(long long rel) const {
+        const int64_t b = block_of_step(rel / 2);
+        return d_draws[b & 1] + (size_t)(rel - 2 * block_start(b)) * ds.n_half;
     }
 };
 
 namespace {
+
+// Enqueue, on stream `gs` (the one the half-steps run on: behind the last reader of the buffer), the generation of
+// `len` steps of draw records starting at absolute step `step0` into buffer `buf`.  `front`: where the slots of the
+// half-step in front of the block come from (null: nothing in front, the start of a run).
+lcf_status generate_steps(lcf_sampler* s, int buf, int64_t step0, int64_t len, int split_mode, const int* host_perm,
+                          bool need_slots, const int* front, hipStream_t gs) {
+    const DevSampler& ds = s->ds;
+    const int* perm = nullptr;
+    if (split_mode == LCF_SPLIT_RANDOM) {
+        int n_pad = 2;
+        while (n_pad < ds.n_walkers) n_pad <<= 1;
+        const int threads = std::min(1024, std::max(64, n_pad / 2));
+        hipLaunchKernelGGL(k_make_perm, dim3((unsigned)len), dim3(threads), (size_t)n_pad * 8, gs, ds.n_walkers, n_pad,
+                           ds.key0, ds.key1, (long long)step0, s->d_perm[buf]);
+        perm = s->d_perm[buf];
+    } else if (split_mode == LCF_SPLIT_HOST) {
+        perm = host_perm;
+    }
+    const long long total = (long long)len * ds.n_walkers;
+    int* slots = nullptr;
+    if (need_slots) {
+        slots = s->d_slot[buf];
+        const size_t row = (size_t)ds.n_walkers * sizeof(int);
+        if (!front)
+            LCF_HIP(hipMemsetAsync(slots, 0xff, row, gs));
+        else
+            LCF_HIP(hipMemcpyAsync(slots, front, row, hipMemcpyDeviceToDevice, gs));
+        hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gs, ds.n_walkers, ds.n_half, perm,
+                           (long long)len, slots);
+    }
+    const long long recs = (long long)len * 2 * ds.n_half;
+    hipLaunchKernelGGL(k_draws, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, gs, ds, perm, slots,
+                       (long long)step0, (long long)len, s->d_draws[buf]);
+    LCF_HIP(hipGetLastError());
+    return LCF_OK;
+}
+
+// Block b of the current run (block b lives in buffer b & 1).
+lcf_status generate_block(lcf_sampler* s, int64_t b, hipStream_t consumer) {
+    const int buf = (int)(b & 1);
+    const int64_t k0 = s->block_start(b);
+    const int* host_perm = s->split_mode == LCF_SPLIT_HOST ? s->d_perm_host + (size_t)k0 * s->ds.n_walkers : nullptr;
+    // the half-step in front of a later block: the last row of the previous block (the other buffer)
+    const int* front = (b > 0 && s->need_slots)
+                           ? s->d_slot[buf ^ 1] + (size_t)2 * s->block_len(b - 1) * s->ds.n_walkers : nullptr;
+    if (lcf_status r = generate_steps(s, buf, s->run_first + k0, s->block_len(b), s->split_mode, host_perm, s->need_slots,
+                                      front, consumer))
+        return r;
+    s->blk_generated = b;
+    return LCF_OK;
+}
+
+// A run usually continues where the last one stopped (burn-in -> sampling; run_mcmc(None, ...) in a loop).  Behind the
+// last launch of a run, generate the first block of such a continuation, so that its first half-step finds its draw
+// records ready: sampler_begin adopts them when the new run matches (first step, split mode, slot bookkeeping).
+lcf_status speculate_continuation(lcf_sampler* s, hipStream_t st) {
+    s->spec_first = -1;
+    if (s->pending || s->split_mode == LCF_SPLIT_HOST || s->run_steps == 0) return LCF_OK;
+    const int64_t first = s->run_first + s->run_steps;
+    if (lcf_status r = generate_steps(s, 0, first, s->blk_first, s->split_mode, nullptr, s->need_slots, nullptr, st))
+        return r;
+    s->spec_first = first;
+    s->spec_mode = s->split_mode;
+    s->spec_slots = s->need_slots;
+    return LCF_OK;
+}
+
+// Before launching the run's half-step `rel` on stream `st`: its block of draw records must be generated (it is,
+// unless the caller jumped ahead).
+lcf_status enter_half_step(lcf_sampler* s, long long rel, hipStream_t st) {
+    const int64_t b = s->block_of_step(rel / 2);
+    if (b == s->blk_current) return LCF_OK;
+    while (s->blk_generated < b)
+        if (lcf_status r = generate_block(s, s->blk_generated + 1, st)) return r;
+    s->blk_current = b;
+    return LCF_OK;
+}
+
+// After that launch (the last reader of the block left behind, through the previous half-step's records): generate
+// the next block into the buffer that is now free.
+lcf_status leave_half_step(lcf_sampler* s, hipStream_t st) {
+    const int64_t last = s->block_of_step(s->run_steps - 1);
+    if (s->blk_generated == s->blk_current && s->blk_current < last)
+        return generate_block(s, s->blk_current + 1, st);
+    return LCF_OK;
+}
 
 template <class T>
 lcf_status dalloc(T** p, size_t n, std::vector<void*>& owned) {
@@ -1418,8 +1767,11 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     if (!have_prev && !have_next) return LCF_OK;
     const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
     const long long rel = g - s->g_run0;
-    const DrawRec* draws = have_next ? s->d_draws + (size_t)rel * ds.n_half : nullptr;
-    const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
+    if (st != e->stream) s->foreign_stream = true;
+    if (have_next)
+        if (lcf_status r = enter_half_step(s, rel, st)) return r;
+    const DrawRec* draws = have_next ? s->rows(rel) : nullptr;
+    const DrawRec* prev_draws = have_prev ? s->rows(rel - 1) : nullptr;
     const bool thermal = have_next && fuse_thermal && e->dp.use_therm && hi > lo;
     const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
     // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then; with it,
@@ -1443,6 +1795,8 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
     }
 #undef LCF_STEP
     LCF_HIP(hipGetLastError());
+    if (have_next)
+        if (lcf_status r = leave_half_step(s, st)) return r;
     s->pending = have_next;
     if (have_next) s->g_next = g + 1;
     return LCF_OK;
@@ -1472,7 +1826,8 @@ size_t fused_lds_bytes(const lcf_engine* e) {
 bool fused_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_FUSED") != nullptr;
     const lcf_engine* e = s->e;
-    return !disabled && e->dp.tab_in_lds && fused_lds_bytes(e) <= 64 * 1024;
+    return !disabled && s->half_step_kernel != LCF_HALF_STEP_PHASES && e->dp.tab_in_lds &&
+           fused_lds_bytes(e) <= 64 * 1024;
 }
 
 // One launch for a whole half-step of a single-GPU run: commit half-step g_next - 1 (if pending), draw half-step
@@ -1484,8 +1839,10 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
     const int have_prev = s->pending ? 1 : 0;
     const long long prev_row = have_prev ? (g - 1 - s->g_run0) / 2 : 0;
     const long long rel = g - s->g_run0;
-    const DrawRec* draws = s->d_draws + (size_t)rel * ds.n_half;
-    const DrawRec* prev_draws = have_prev ? s->d_draws + (size_t)(rel - 1) * ds.n_half : nullptr;
+    if (st != e->stream) s->foreign_stream = true;
+    if (lcf_status r = enter_half_step(s, rel, st)) return r;
+    const DrawRec* draws = s->rows(rel);
+    const DrawRec* prev_draws = have_prev ? s->rows(rel - 1) : nullptr;
     const int foreign = ds.n_half - (hi - lo);
     const dim3 grid((unsigned)((size_t)(hi - lo) * e->dp.n_parts + (foreign + kBlock / 64 - 1) / (kBlock / 64)));
     const size_t lds = fused_lds_bytes(e);
@@ -1509,9 +1866,75 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
 #undef LCF_FUSED
 #undef LCF_FUSED3
     LCF_HIP(hipGetLastError());
+    if (lcf_status r = leave_half_step(s, st)) return r;
     s->pending = true;
     s->g_next = g + 1;
     return LCF_OK;
+}
+
+// ---- one workgroup per proposal (k_solo): single-GPU runs whose parts fit one workgroup -----------------------------
+size_t solo_lds_bytes(const lcf_engine* e) {
+    return (kExpTabSize + 16) * sizeof(double) + (size_t)e->dp.n_lds_tab * sizeof(double2) +
+           (size_t)e->dp.n_filters * sizeof(FiltDesc) + (kSoloScratch + 4) * sizeof(double) +
+           (e->dp.use_therm ? (size_t)e->dp.n_epochs * sizeof(double2) : 0);
+}
+
+constexpr size_t kLdsPerCU = 160 * 1024;
+
+bool solo_eligible(const lcf_sampler* s) {
+    static const bool disabled = std::getenv("LCF_NO_SOLO") != nullptr;
+    const lcf_engine* e = s->e;
+    // (the libm band sum, variant 0, exists to mirror the reference instruction for instruction: it keeps k_fused)
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
+}
+
+// One half-step of a single-GPU run: ONE launch, one workgroup per proposal, accept test and commit included.
+lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
+    lcf_engine* e = s->e;
+    const DevSampler& ds = s->ds;
+    if (lcf_status r = enter_half_step(s, rel, st)) return r;
+    const DrawRec* draws = s->rows(rel);
+    const bool next_here = rel + 1 < 2 * s->run_steps && s->block_of_step((rel + 1) / 2) == s->blk_current;
+    const DrawRec* draws_next = next_here ? draws + ds.n_half : nullptr;
+    const size_t lds = solo_lds_bytes(e);
+    const long long row = rel / 2;
+    const dim3 grid((unsigned)ds.n_half);
+#define LCF_SOLO4(ND, V, T, NP)                                                                                       \
+    do {                                                                                                              \
+        if (lds > 64 * 1024) {                                                                                        \
+            static bool raised = false; /* per instantiation: allow more than the default 64 KiB of dynamic LDS */   \
+            if (!raised) {                                                                                            \
+                LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP>,                                        \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));             \
+                raised = true;                                                                                        \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_solo<ND, V, T, NP>), grid, dim3(kBlock * NP), lds, st, e->dp, ds, row, draws,           \
+                           draws_next);                                                                               \
+    } while (0)
+    // workgroups of 512 threads (up to two parts) or 1024 (three or four)
+#define LCF_SOLO3(ND, V, T)                                                                                           \
+    do {                                                                                                              \
+        if (e->dp.n_parts <= 2) LCF_SOLO4(ND, V, T, 2); else LCF_SOLO4(ND, V, T, 4);                                  \
+    } while (0)
+#define LCF_SOLO(ND)                                                                                                  \
+    do {                                                                                                              \
+        if (e->dp.use_therm) LCF_SOLO3(ND, 1, true); else LCF_SOLO3(ND, 1, false);                                    \
+    } while (0)
+    switch (ds.n_dim) {
+        case 4: LCF_SOLO(4); break;
+        case 5: LCF_SOLO(5); break;
+        case 6: LCF_SOLO(6); break;
+        case 7: LCF_SOLO(7); break;
+        case 8: LCF_SOLO(8); break;
+        case 9: LCF_SOLO(9); break;
+        default: LCF_SOLO(0); break;
+    }
+#undef LCF_SOLO
+#undef LCF_SOLO3
+#undef LCF_SOLO4
+    LCF_HIP(hipGetLastError());
+    return leave_half_step(s, st);
 }
 
 // Log-posteriors of the shard's proposals from their partial sums (sharded runs: the all-gather sends these).
@@ -1547,6 +1970,139 @@ lcf_status flush_pending(lcf_sampler* s, hipStream_t st) {
     return launch_next(s, false, false, 0, 0, st);
 }
 
+// Commit what is pending and copy the snapshot behind it, all on the engine's stream; enqueue only.
+lcf_status enqueue_snapshot(lcf_sampler* s) {
+    lcf_engine* e = s->e;
+    hipStream_t st = e->stream;
+    if (s->foreign_stream) {  // half-steps were driven on a caller's stream: order this stream behind them
+        LCF_HIP(hipDeviceSynchronize());
+        s->foreign_stream = false;
+    }
+    if (lcf_status r = flush_pending(s, st)) return r;
+    const DevSampler& ds = s->ds;
+    // one small kernel writes the snapshot straight into the pinned host buffer (four separate copies cost 4x the
+    // fixed price of a device-to-host transfer)
+    const long long words = (long long)(s->snap_bytes() / 8);
+    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ds,
+                       reinterpret_cast<unsigned long long*>(s->snap));
+    LCF_HIP(hipGetLastError());
+    s->snap_enqueued = true;
+    s->snap_valid = false;
+    return LCF_OK;
+}
+
+// The snapshot of the sampler's present state, complete in host memory on return.
+lcf_status settle(lcf_sampler* s) {
+    LCF_HIP(hipSetDevice(s->e->device));
+    if (s->snap_valid && !s->pending && !s->foreign_stream) return LCF_OK;
+    if (!s->snap_enqueued || s->pending || s->foreign_stream)
+        if (lcf_status r = enqueue_snapshot(s)) return r;
+    LCF_HIP(hipStreamSynchronize(s->e->stream));
+    s->snap_enqueued = false;
+    s->snap_valid = true;
+    return LCF_OK;
+}
+
+// Whatever changes the state on the device makes the host's copy stale.
+void invalidate_snapshot(lcf_sampler* s) { s->snap_enqueued = s->snap_valid = false; }
+
+// Start a run of n_steps steps: settle what the previous run left pending, size the chain and the draw blocks, and
+// enqueue the generation of the first block.  Nothing here waits for the device unless a buffer has to grow.
+// `need_slots`: the draw records carry each walker's slot in the previous half-step (every path except k_solo).
+lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode, const int32_t* perm,
+                         int32_t store_chain, bool need_slots) {
+    if (!s || n_steps < 0 || first_step < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    if (split_mode < LCF_SPLIT_IDENTITY || split_mode > LCF_SPLIT_HOST)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad split_mode");
+    if (split_mode == LCF_SPLIT_HOST && !perm && n_steps > 0)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "LCF_SPLIT_HOST needs perm");
+    if (split_mode == LCF_SPLIT_RANDOM && s->ds.n_walkers > 16384)
+        return fail(LCF_ERR_UNSUPPORTED, "device-generated splits support at most 16384 walkers; pass perm");
+    if (split_mode != LCF_SPLIT_HOST) perm = nullptr;
+    if (!s->has_state) return fail(LCF_ERR_STATE, "lcf_sampler_set_state must be called first");
+    lcf_engine* e = s->e;
+    LCF_HIP(hipSetDevice(e->device));
+    if (s->foreign_stream) {  // the previous run was driven on a caller's stream: order everything behind it
+        LCF_HIP(hipDeviceSynchronize());
+        s->foreign_stream = false;
+    }
+    if (lcf_status st = flush_pending(s, e->stream)) return st;  // with the previous run's chain and draw records
+    DevSampler& ds = s->ds;
+    // leave a gap in the half-step numbering: no stale (last_g == g - 1) match across runs or set_state calls
+    s->g_next += 2;
+    s->g_run0 = s->g_next;
+    ds.store_chain = store_chain ? 1 : 0;
+    if (store_chain && n_steps > s->chain_cap) {
+        LCF_HIP(hipStreamSynchronize(e->stream));
+        if (ds.chain) hipFree(ds.chain);
+        if (ds.chain_lp) hipFree(ds.chain_lp);
+        ds.chain = nullptr;
+        ds.chain_lp = nullptr;
+        s->chain_cap = 0;
+        LCF_HIP(hipMalloc((void**)&ds.chain, (size_t)n_steps * ds.n_walkers * ds.n_dim * sizeof(double)));
+        LCF_HIP(hipMalloc((void**)&ds.chain_lp, (size_t)n_steps * ds.n_walkers * sizeof(double)));
+        s->chain_cap = n_steps;
+    }
+    if (perm && n_steps > 0) {
+        // validate: every row must be a permutation of 0..n_walkers-1 (out-of-range ids would fault the GPU)
+        std::vector<char> seen(ds.n_walkers);
+        for (int64_t r = 0; r < n_steps; ++r) {
+            std::fill(seen.begin(), seen.end(), 0);
+            const int32_t* row = perm + (size_t)r * ds.n_walkers;
+            for (int i = 0; i < ds.n_walkers; ++i) {
+                if (row[i] < 0 || row[i] >= ds.n_walkers || seen[row[i]])
+                    return fail(LCF_ERR_INVALID_ARGUMENT, "perm rows must be permutations of the walker ids");
+                seen[row[i]] = 1;
+            }
+        }
+        LCF_HIP(hipStreamSynchronize(e->stream));
+        if (n_steps > s->perm_host_rows) {
+            if (s->d_perm_host) hipFree(s->d_perm_host);
+            s->d_perm_host = nullptr;
+            s->perm_host_rows = 0;
+            LCF_HIP(hipMalloc((void**)&s->d_perm_host, (size_t)n_steps * ds.n_walkers * sizeof(int)));
+            s->perm_host_rows = n_steps;
+        }
+        LCF_HIP(hipMemcpy(s->d_perm_host, perm, (size_t)n_steps * ds.n_walkers * sizeof(int), hipMemcpyHostToDevice));
+    }
+    invalidate_snapshot(s);
+    s->run_first = first_step;
+    s->run_steps = n_steps;
+    s->split_mode = split_mode;
+    s->need_slots = need_slots;
+    s->blk_generated = s->blk_current = -1;
+    if (n_steps == 0) return LCF_OK;
+    // Block geometry: about 2^18 draw records (12 MiB) per buffer however long the run; a short first block, so that
+    // the first half-step waits for a few steps' worth of records only.
+    int64_t cap = std::max<int64_t>(4, std::min<int64_t>(256, (int64_t)(1 << 18) / ds.n_walkers));
+    if (const char* env = std::getenv("LCF_DRAW_BLOCK")) cap = std::max<int64_t>(1, std::atoll(env));  // (tests: tiny blocks)
+    bool grown = false;
+    if (cap > s->blk_cap) {
+        grown = true;
+        LCF_HIP(hipStreamSynchronize(e->stream));
+        s->free_blocks();
+        for (int b = 0; b < 2; ++b) {
+            LCF_HIP(hipMalloc((void**)&s->d_perm[b], (size_t)cap * ds.n_walkers * sizeof(int)));
+            LCF_HIP(hipMalloc((void**)&s->d_draws[b], (size_t)cap * 2 * ds.n_half * sizeof(DrawRec)));
+            LCF_HIP(hipMalloc((void**)&s->d_slot[b], (size_t)(1 + 2 * cap) * ds.n_walkers * sizeof(int)));
+        }
+        s->blk_cap = cap;
+        int n_pad = 2;
+        while (n_pad < ds.n_walkers) n_pad <<= 1;
+        if ((size_t)n_pad * 8 > 65536)
+            LCF_HIP(hipFuncSetAttribute((const void*)k_make_perm, hipFuncAttributeMaxDynamicSharedMemorySize, n_pad * 8));
+    }
+    s->blk_steps = s->blk_cap;
+    s->blk_first = std::min<int64_t>(s->blk_cap, 8);
+    if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown) {
+        s->spec_first = -1;  // the previous run left this run's first block behind (speculate_continuation)
+        s->blk_generated = 0;
+        return LCF_OK;
+    }
+    s->spec_first = -1;
+    return generate_block(s, 0, e->stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1554,14 +2110,14 @@ extern "C" {
 lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, double a, lcf_sampler** out) {
     if (!e || !out) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (n_walkers < 2 || (n_walkers & 1)) return fail(LCF_ERR_INVALID_ARGUMENT, "n_walkers must be even and >= 2");
+    if (n_walkers < 2) return fail(LCF_ERR_INVALID_ARGUMENT, "n_walkers must be >= 2");
     if (!(a > 1.)) return fail(LCF_ERR_INVALID_ARGUMENT, "stretch scale a must be > 1");
     LCF_HIP(hipSetDevice(e->device));
     auto* s = new lcf_sampler();
     s->e = e;
     DevSampler& ds = s->ds;
     ds.n_walkers = n_walkers;
-    ds.n_half = n_walkers / 2;
+    ds.n_half = (n_walkers + 1) / 2;  // slots per half-step: the larger colour of an odd ensemble
     ds.n_dim = e->dp.n_dim;
     ds.key0 = (uint32_t)(seed & 0xffffffffu);
     ds.key1 = (uint32_t)(seed >> 32);
@@ -1581,6 +2137,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
     LCF_HIP(hipEventCreate(&s->ev0));
     LCF_HIP(hipEventCreate(&s->ev1));
+    LCF_HIP(hipHostMalloc((void**)&s->snap, s->snap_bytes(), hipHostMallocDefault));
     *out = s;
     return LCF_OK;
 }
@@ -1593,6 +2150,8 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     LCF_HIP(hipSetDevice(e->device));
     LCF_HIP(hipDeviceSynchronize());
     s->pending = false;  // an uncommitted move of the old state is dropped with it
+    s->foreign_stream = false;
+    invalidate_snapshot(s);
     const DevSampler& ds = s->ds;
     if (lcf_status st = e->reserve(ds.n_walkers)) return st;
     LCF_HIP(hipMemcpyAsync(ds.X, coords, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -1606,106 +2165,18 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
 
 lcf_status lcf_sampler_get_state(lcf_sampler* s, double* coords, double* log_prob) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    LCF_HIP(hipSetDevice(s->e->device));
-    LCF_HIP(hipDeviceSynchronize());
-    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
-    LCF_HIP(hipDeviceSynchronize());
-    const DevSampler& ds = s->ds;
-    if (coords) LCF_HIP(hipMemcpy(coords, ds.X, (size_t)ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
-    if (log_prob) LCF_HIP(hipMemcpy(log_prob, ds.LP, (size_t)ds.n_walkers * sizeof(double), hipMemcpyDeviceToHost));
+    if (lcf_status st = settle(s)) return st;
+    if (coords) std::memcpy(coords, s->snap + s->snap_x(), s->snap_lp() - s->snap_x());
+    if (log_prob) std::memcpy(log_prob, s->snap + s->snap_lp(), s->snap_acc() - s->snap_lp());
     return LCF_OK;
 }
 
 lcf_status lcf_sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                              const int32_t* perm, int32_t store_chain) {
-    if (!s || n_steps < 0 || first_step < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
-    if (split_mode < LCF_SPLIT_IDENTITY || split_mode > LCF_SPLIT_HOST)
-        return fail(LCF_ERR_INVALID_ARGUMENT, "bad split_mode");
-    if (split_mode == LCF_SPLIT_HOST && !perm && n_steps > 0)
-        return fail(LCF_ERR_INVALID_ARGUMENT, "LCF_SPLIT_HOST needs perm");
-    if (split_mode == LCF_SPLIT_RANDOM && s->ds.n_walkers > 16384)
-        return fail(LCF_ERR_UNSUPPORTED, "device-generated splits support at most 16384 walkers; pass perm");
-    if (split_mode != LCF_SPLIT_HOST) perm = nullptr;
-    if (!s->has_state) return fail(LCF_ERR_STATE, "lcf_sampler_set_state must be called first");
-    lcf_engine* e = s->e;
-    LCF_HIP(hipSetDevice(e->device));
-    LCF_HIP(hipDeviceSynchronize());
-    if (lcf_status st = flush_pending(s, e->stream)) return st;  // with the previous run's chain/perm settings
-    LCF_HIP(hipDeviceSynchronize());
-    DevSampler& ds = s->ds;
-    s->run_first = first_step;
-    s->run_steps = n_steps;
-    // leave a gap in the half-step numbering: no stale (last_g == g - 1) match across runs or set_state calls
-    s->g_next += 2;
-    s->g_run0 = s->g_next;
-    ds.store_chain = store_chain ? 1 : 0;
-    if (store_chain && n_steps > s->chain_cap) {
-        if (ds.chain) hipFree(ds.chain);
-        if (ds.chain_lp) hipFree(ds.chain_lp);
-        ds.chain = nullptr;
-        ds.chain_lp = nullptr;
-        s->chain_cap = 0;
-        LCF_HIP(hipMalloc((void**)&ds.chain, (size_t)n_steps * ds.n_walkers * ds.n_dim * sizeof(double)));
-        LCF_HIP(hipMalloc((void**)&ds.chain_lp, (size_t)n_steps * ds.n_walkers * sizeof(double)));
-        s->chain_cap = n_steps;
-    }
-    s->have_perm = split_mode != LCF_SPLIT_IDENTITY;
-    if (s->have_perm && n_steps > 0) {
-        if (n_steps > s->perm_rows) {
-            if (s->d_perm) hipFree(s->d_perm);
-            s->d_perm = nullptr;
-            s->perm_rows = 0;
-            LCF_HIP(hipMalloc((void**)&s->d_perm, (size_t)n_steps * ds.n_walkers * sizeof(int)));
-            s->perm_rows = n_steps;
-        }
-    }
-    if (split_mode == LCF_SPLIT_RANDOM && n_steps > 0) {
-        int n_pad = 2;
-        while (n_pad < ds.n_walkers) n_pad <<= 1;
-        const int threads = std::min(1024, std::max(64, n_pad / 2));
-        if ((size_t)n_pad * 8 > 65536)
-            LCF_HIP(hipFuncSetAttribute((const void*)k_make_perm, hipFuncAttributeMaxDynamicSharedMemorySize, n_pad * 8));
-        hipLaunchKernelGGL(k_make_perm, dim3((unsigned)n_steps), dim3(threads), (size_t)n_pad * 8, e->stream,
-                           ds.n_walkers, n_pad, ds.key0, ds.key1, (long long)first_step, s->d_perm);
-        LCF_HIP(hipGetLastError());
-        LCF_HIP(hipStreamSynchronize(e->stream));
-    }
-    if (perm && n_steps > 0) {
-        // validate: every row must be a permutation of 0..n_walkers-1 (out-of-range ids would fault the GPU)
-        std::vector<char> seen(ds.n_walkers);
-        for (int64_t r = 0; r < n_steps; ++r) {
-            std::fill(seen.begin(), seen.end(), 0);
-            const int32_t* row = perm + (size_t)r * ds.n_walkers;
-            for (int i = 0; i < ds.n_walkers; ++i) {
-                if (row[i] < 0 || row[i] >= ds.n_walkers || seen[row[i]])
-                    return fail(LCF_ERR_INVALID_ARGUMENT, "perm rows must be permutations of the walker ids");
-                seen[row[i]] = 1;
-            }
-        }
-        LCF_HIP(hipMemcpy(s->d_perm, perm, (size_t)n_steps * ds.n_walkers * sizeof(int), hipMemcpyHostToDevice));
-    }
-    if (n_steps > 0) {  // state-independent draws of the whole run: (walker, partner, z, ln u) per proposal slot
-        if (n_steps > s->draw_rows) {
-            if (s->d_draws) hipFree(s->d_draws);
-            s->d_draws = nullptr;
-            s->draw_rows = 0;
-            LCF_HIP(hipMalloc((void**)&s->d_draws, (size_t)n_steps * ds.n_walkers * sizeof(DrawRec)));
-            s->draw_rows = n_steps;
-        }
-        const long long total = (long long)n_steps * ds.n_walkers;
-        int* slot_of = nullptr;  // [n_steps][2][n_walkers], scratch for this call only
-        LCF_HIP(hipMalloc((void**)&slot_of, (size_t)total * 2 * sizeof(int)));
-        const int* dperm = s->have_perm ? s->d_perm : nullptr;
-        hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds.n_walkers,
-                           ds.n_half, dperm, (long long)n_steps, slot_of);
-        hipLaunchKernelGGL(k_draws, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e->stream, ds, dperm, slot_of,
-                           (long long)first_step, (long long)n_steps, s->d_draws);
-        const hipError_t lerr = hipGetLastError();
-        const hipError_t serr = hipStreamSynchronize(e->stream);
-        hipFree(slot_of);
-        LCF_HIP(lerr);
-        LCF_HIP(serr);
-    }
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, true)) return st;
+    // the half-steps of the phase API may be enqueued on a caller's stream, which is not ordered with the engine's own:
+    // the first block of draw records (generated on the engine's stream) must be complete before this returns
+    LCF_HIP(hipStreamSynchronize(s->e->stream));
     return LCF_OK;
 }
 
@@ -1747,7 +2218,15 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
     return LCF_OK;
 }
 void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
-int32_t lcf_sampler_one_launch(const lcf_sampler* s) { return s && fused_eligible(s) ? 1 : 0; }
+lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used) {
+    if (!s || choice < LCF_HALF_STEP_AUTO || choice > LCF_HALF_STEP_PHASES)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad half-step kernel choice");
+    s->half_step_kernel = choice;
+    if (used) *used = solo_eligible(s) ? 2 : fused_eligible(s) ? 1 : 0;
+    return LCF_OK;
+}
+
+int32_t lcf_sampler_one_launch(const lcf_sampler* s) { return s && (solo_eligible(s) || fused_eligible(s)) ? 1 : 0; }
 
 lcf_status lcf_sampler_half_step_rows(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi,
                                       void* stream) {
@@ -1769,12 +2248,9 @@ void* lcf_sampler_rows_ptr(lcf_sampler* s, int32_t* row_doubles) {
 
 lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    LCF_HIP(hipSetDevice(s->e->device));
-    LCF_HIP(hipDeviceSynchronize());
-    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
-    LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = settle(s)) return st;
     int err = 0;
-    LCF_HIP(hipMemcpy(&err, s->ds.err, sizeof(int), hipMemcpyDeviceToHost));
+    std::memcpy(&err, s->snap, sizeof(int));
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;
 }
@@ -1787,6 +2263,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, lcf_comm_id, int) = nullptr;  // ncclUniqueId is a 128-byte struct by value
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -1802,6 +2280,8 @@ lcf_status rccl_load(const char* path) {
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(h, "ncclCommUserRank");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
         return fail(LCF_ERR_UNSUPPORTED, "RCCL library lacks the expected symbols");
     g_rccl = r;
@@ -1844,6 +2324,44 @@ lcf_status lcf_comm_create(const char* rccl_path, const lcf_comm_id* id, int32_t
     return LCF_OK;
 }
 
+lcf_status lcf_comm_count(const lcf_comm* c, int32_t* n_ranks, int32_t* rank) {
+    if (!c || !c->comm) return fail(LCF_ERR_INVALID_ARGUMENT, "null communicator");
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(LCF_ERR_UNSUPPORTED, "RCCL lacks ncclCommCount");
+    int n = 0, r = 0;
+    if (lcf_status st = rccl_check(g_rccl.CommCount(c->comm, &n), "ncclCommCount")) return st;
+    if (lcf_status st = rccl_check(g_rccl.CommUserRank(c->comm, &r), "ncclCommUserRank")) return st;
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    return LCF_OK;
+}
+
+lcf_status lcf_comm_time_allgather(lcf_comm* c, lcf_sampler* s, int32_t reps, double* avg_ms) {
+    if (!c || !s || reps <= 0 || !avg_ms) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    const int nh = s->ds.n_half;
+    if (nh % c->n_ranks) return fail(LCF_ERR_INVALID_ARGUMENT, "the slots of a half-step must divide evenly over the ranks");
+    LCF_HIP(hipSetDevice(s->e->device));
+    hipStream_t st = s->e->stream;
+    const size_t stride = (size_t)s->e->dp.n_parts + 1, width = (size_t)(nh / c->n_ranks);
+    double* scratch = nullptr;  // not the sampler's rows: a measurement must not disturb a chain
+    LCF_HIP(hipMalloc((void**)&scratch, (size_t)nh * stride * sizeof(double)));
+    LCF_HIP(hipMemsetAsync(scratch, 0, (size_t)nh * stride * sizeof(double), st));
+    lcf_status rc = LCF_OK;
+    for (int k = -2; k < reps && rc == LCF_OK; ++k) {  // two warm-up rounds, then the timed ones
+        if (k == 0 && hipEventRecord(s->ev0, st) != hipSuccess) rc = fail(LCF_ERR_HIP, "hipEventRecord");
+        if (rc == LCF_OK)
+            rc = rccl_check(g_rccl.AllGather(scratch + c->rank * width * stride, scratch, width * stride, /*ncclDouble*/ 8,
+                                             c->comm, st), "ncclAllGather");
+    }
+    if (rc == LCF_OK && hipEventRecord(s->ev1, st) != hipSuccess) rc = fail(LCF_ERR_HIP, "hipEventRecord");
+    const hipError_t serr = hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (rc == LCF_OK && serr == hipSuccess && hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) *avg_ms = ms / reps;
+    hipFree(scratch);
+    if (rc != LCF_OK) return rc;
+    LCF_HIP(serr);
+    return LCF_OK;
+}
+
 void lcf_comm_destroy(lcf_comm* c) {
     if (!c) return;
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -1857,7 +2375,8 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
                                    int32_t split_mode, const int32_t* perm, int32_t store_chain) {
     if (!s || !c) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     const int nh = s->ds.n_half;
-    if (nh % c->n_ranks) return fail(LCF_ERR_INVALID_ARGUMENT, "n_walkers / 2 must be divisible by the number of ranks");
+    if (nh % c->n_ranks)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "the slots of a half-step must divide evenly over the ranks");
     if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     hipStream_t st = s->e->stream;
     const int width = nh / c->n_ranks, lo = c->rank * width, hi = lo + width;
@@ -1876,6 +2395,7 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     }
     if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
+    if (lcf_status r = enqueue_snapshot(s)) return r;
     return lcf_sampler_wait(s);
 }
 
@@ -1883,13 +2403,22 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
 // population) then execute concurrently on the device.  lcf_sampler_wait() completes it.
 lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                                  const int32_t* perm, int32_t store_chain) {
-    if (lcf_status st = lcf_sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, !solo_eligible(s))) return st;
     hipStream_t st = s->e->stream;
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
     // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else
     // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
     const bool fused = fused_eligible(s);
+    if (solo_eligible(s)) {  // one workgroup per proposal, nothing pending between launches
+        for (int64_t k = 0; k < 2 * n_steps; ++k)
+            if (lcf_status r = launch_solo(s, k, st)) return r;
+        s->g_next += 2 * n_steps;
+        LCF_HIP(hipEventRecord(s->ev1, st));
+        if (lcf_status r = enqueue_snapshot(s)) return r;
+        return speculate_continuation(s, st);
+    }
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
         if (fused) {
             if (lcf_status r = launch_fused(s, 0, s->ds.n_half, st)) return r;
@@ -1900,16 +2429,16 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     }
     if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
-    return LCF_OK;
+    if (lcf_status r = enqueue_snapshot(s)) return r;
+    return speculate_continuation(s, st);
 }
 
 lcf_status lcf_sampler_wait(lcf_sampler* s) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    LCF_HIP(hipSetDevice(s->e->device));
-    LCF_HIP(hipStreamSynchronize(s->e->stream));
+    if (lcf_status st = lcf_sampler_check(s)) return st;  // (waits for the run and its snapshot)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_ms = ms;
-    return lcf_sampler_check(s);
+    return LCF_OK;
 }
 
 lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
@@ -1952,7 +2481,8 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         lcf_sampler* s = ss[t];
         s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
         s->ds.inline_finalize = 1;
-        items[t] = MultiItem{s->e->dp, s->ds, s->d_draws, s->coef, s->lprior, s->therm};
+        items[t] = MultiItem{s->e->dp, s->ds, {s->d_draws[0], s->d_draws[1]}, (long long)s->blk_first,
+                             (long long)s->blk_steps, s->coef, s->lprior, s->therm};
         // With many transients in one launch a single workgroup per proposal already fills the chip, and it stages
         // the tables and reduces once for all of the proposal's chunks: fewer parts than the engine's default.
         DevProblem& ip = items[t].pb;
@@ -1984,6 +2514,10 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int64_t k = 0; k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
+        if (have_next)  // every transient's block of draw records resident for this stream
+            for (int t = 0; t < n && err == hipSuccess; ++t)
+                if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
+        if (err != hipSuccess) break;
 #define LCF_STEPM(ND) hipLaunchKernelGGL(k_step_multi<ND>, have_next ? gs : dim3((unsigned)nh, (unsigned)n),              \
                                          have_next ? bs : dim3(64), 0, st, ditems, have_prev ? 1 : 0,                  \
                                          (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k, (long long)(g + k), \
@@ -1996,6 +2530,11 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             default: LCF_STEPM(0); break;
         }
 #undef LCF_STEPM
+        if (have_next)
+            for (int t = 0; t < n && err == hipSuccess; ++t) {
+                if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
+                if (leave_half_step(ss[t], st) != LCF_OK) err = hipErrorUnknown;
+            }
         if (!have_next) break;
         const int parity = (int)((g + k) & 1);
 #define LCF_PM(V, L, T) hipLaunchKernelGGL((k_points_multi<V, L, T>), gp, bp, lds, st, ditems, parity)
@@ -2028,10 +2567,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     if (!s->ds.store_chain || s->run_steps == 0) return fail(LCF_ERR_STATE, "no stored chain");
-    LCF_HIP(hipSetDevice(s->e->device));
-    LCF_HIP(hipDeviceSynchronize());
-    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
-    LCF_HIP(hipDeviceSynchronize());
+    if (lcf_status st = settle(s)) return st;  // (the trailing commit writes the last chain row)
     const DevSampler& ds = s->ds;
     if (chain)
         LCF_HIP(hipMemcpy(chain, ds.chain, (size_t)s->run_steps * ds.n_walkers * ds.n_dim * sizeof(double), hipMemcpyDeviceToHost));
@@ -2042,14 +2578,17 @@ lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob
 
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted) {
     if (!s || !n_accepted) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    LCF_HIP(hipSetDevice(s->e->device));
-    LCF_HIP(hipDeviceSynchronize());
-    if (lcf_status st = flush_pending(s, s->e->stream)) return st;
-    LCF_HIP(hipDeviceSynchronize());
-    LCF_HIP(hipMemcpy(n_accepted, s->ds.nacc, (size_t)s->ds.n_walkers * sizeof(long long), hipMemcpyDeviceToHost));
+    if (lcf_status st = settle(s)) return st;
+    std::memcpy(n_accepted, s->snap + s->snap_acc(), s->snap_bytes() - s->snap_acc());
     return LCF_OK;
 }
 
 double lcf_sampler_last_run_ms(const lcf_sampler* s) { return s ? s->last_ms : 0.; }
 
 }  // extern "C"
+
+#ifdef LCF_STAMPS
+extern "C" int lcf_debug_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif

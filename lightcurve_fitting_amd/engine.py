@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 4
+LCF_ABI_VERSION = 5
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -99,6 +99,7 @@ SIGNATURES = [
     ('lcf_sampler_half_step', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_one_launch', C.c_int32, [C.c_void_p]),
+    ('lcf_sampler_set_half_step_kernel', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ('lcf_sampler_half_step_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_rows_ptr', C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
@@ -106,6 +107,8 @@ SIGNATURES = [
     ('lcf_comm_unique_id', C.c_int, [C.c_char_p, C.c_void_p]),
     ('lcf_comm_create', C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_comm_destroy', None, [C.c_void_p]),
+    ('lcf_comm_count', C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ('lcf_comm_time_allgather', C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _dp]),
     ('lcf_sampler_run_sharded', C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_sed_destroy', None, [C.c_void_p]),
@@ -229,9 +232,10 @@ class Engine:
         self.samples_per_eval = lib.lcf_engine_samples_per_eval(self._h)
 
     def close(self):
-        if getattr(self, '_h', None) and self._h.value:
-            self._lib.lcf_engine_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._h = None   # (no module global is touched here: this also runs at interpreter shutdown)
+            self._lib.lcf_engine_destroy(h)
 
     __del__ = close
 
@@ -309,9 +313,10 @@ class NativeSampler:
                                             float(a), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, '_h', None) and self._h.value:
-            self._lib.lcf_sampler_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._h = None   # (no module global is touched here: this also runs at interpreter shutdown)
+            self._lib.lcf_sampler_destroy(h)
 
     __del__ = close
 
@@ -383,6 +388,15 @@ class NativeSampler:
     def one_launch(self):
         """True if a half-step of this sampler is a single kernel launch (see ``lcf_sampler_one_launch``)."""
         return bool(self._lib.lcf_sampler_one_launch(self._h))
+
+    def set_half_step_kernel(self, choice='auto'):
+        """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'fused' | 'phases'; same chain bit
+        for bit).  Returns what a run uses now: 'solo' (one workgroup per proposal, accept test included), 'fused'
+        (one workgroup per proposal and part) or 'phases' (proposal + likelihood launches)."""
+        used = C.c_int32()
+        _check(self._lib.lcf_sampler_set_half_step_kernel(self._h, {'auto': 0, 'fused': 1, 'phases': 2}[choice],
+                                                          C.byref(used)))
+        return {2: 'solo', 1: 'fused', 0: 'phases'}[used.value]
 
     def half_step_rows(self, step, half, lo, hi, stream=0):
         _check(self._lib.lcf_sampler_half_step_rows(self._h, int(step), int(half), int(lo), int(hi),
@@ -458,10 +472,23 @@ class NativeComm:
         self._h = C.c_void_p()
         _check(self._lib.lcf_comm_create(path, uid, self.world, self.rank, int(device), C.byref(self._h)))
 
+    def count(self):
+        """(number of ranks, this rank) as RCCL's communicator reports them."""
+        n, r = C.c_int32(), C.c_int32()
+        _check(self._lib.lcf_comm_count(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
+    def time_allgather(self, native_sampler, reps=200):
+        """Average ms of one per-half-step all-gather of ``native_sampler``'s rows (collective call)."""
+        ms = C.c_double()
+        _check(self._lib.lcf_comm_time_allgather(self._h, native_sampler._h, int(reps), C.byref(ms)))
+        return ms.value
+
     def close(self):
-        if getattr(self, '_h', None) and self._h.value:
-            self._lib.lcf_comm_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._h = None   # (no module global is touched here: this also runs at interpreter shutdown)
+            self._lib.lcf_comm_destroy(h)
 
     __del__ = close
 
@@ -485,9 +512,10 @@ class SedEngine:
         self.last_kernel_ms = 0.
 
     def close(self):
-        if getattr(self, '_h', None) and self._h.value:
-            self._lib.lcf_sed_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self._h = None   # (no module global is touched here: this also runs at interpreter shutdown)
+            self._lib.lcf_sed_destroy(h)
 
     __del__ = close
 

@@ -46,7 +46,7 @@ class NativeBackend:
 
     def __init__(self, native_sampler, rows=False):
         self.ns = native_sampler
-        self.n_half = native_sampler.nwalkers // 2
+        self.n_half = (native_sampler.nwalkers + 1) // 2   # slots per half-step (an odd ensemble's larger colour)
         #: what the collective carries per proposal: its row of partial chi^2 sums + log-prior (no finalize launch;
         #: the protocol of the native ``lcf_sampler_run_sharded``), or its finished log-posterior
         self.rows = bool(rows)
@@ -260,8 +260,9 @@ class EnsembleSampler:
     def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None,
                  force_sharded=False, native_collectives=True):
         from .engine import NativeSampler
-        if nwalkers % 2 or nwalkers < 2 * ndim:
-            raise ValueError('nwalkers must be even and at least 2 * ndim (emcee requirement)')
+        if nwalkers < 2 * ndim:  # emcee's check; odd ensembles are fine (the red-blue split is then ceil / floor)
+            raise ValueError('It is unadvisable to use a red-blue move with fewer walkers than twice the number of '
+                             'dimensions.')
         if ndim != engine.ndim:
             raise ValueError(f'ndim = {ndim} but the engine has {engine.ndim} parameters')
         self.nwalkers, self.ndim = nwalkers, ndim
@@ -301,7 +302,7 @@ class EnsembleSampler:
             # 1. everything that can fail locally (options, shard shape, binding RCCL) BEFORE any collective RCCL call,
             #    so that no rank is left waiting in ncclCommInitRank for one that bailed out
             comm = None
-            if agreed(self.native_collectives and (self.nwalkers // 2) % world == 0 and NativeComm.probe()):
+            if agreed(self.native_collectives and ((self.nwalkers + 1) // 2) % world == 0 and NativeComm.probe()):
                 try:
                     comm = NativeComm(self.engine.device, self._group)
                 except Exception:  # noqa: BLE001 - then every rank falls back to the torch.distributed path

@@ -282,13 +282,12 @@ class CompanionShockingOracle:
     def stretched_sifto(self, t_in, bands, t_peak, stretch, dtU=None, dti=None):
         """Pointwise branch, scalar parameters.  models.py:808-827"""
         out = np.empty(len(bands))
-        for i, (t, b) in enumerate(zip(np.asarray(t_in, dtype=np.float64) - t_peak, bands)):
-            dt = 0.
-            if b.name == 'U' and dtU is not None:
-                dt = dtU
-            elif b.name == 'i' and dti is not None:
-                dt = dti
-            out[i] = self.splines[b.name]((t - dt) / stretch)
+        t = np.asarray(t_in, dtype=np.float64) - t_peak
+        names = np.array([b.name for b in bands])
+        for nm in dict.fromkeys(names.tolist()):  # the reference loops over points; one spline call per band
+            rows = names == nm                    # evaluates the same piecewise cubic on the same arguments
+            dt = dtU if (nm == 'U' and dtU is not None) else dti if (nm == 'i' and dti is not None) else 0.
+            out[rows] = self.splines[nm]((t[rows] - dt) / stretch)
         out[np.isnan(out)] = 0.
         return out
 
@@ -486,7 +485,7 @@ def stretch_move_run(log_prob_fn, coords, nsteps, seed, a=2., log_prob0=None, ra
     chain = np.empty((nsteps, nw, ndim))
     lps = np.empty((nsteps, nw))
     nacc = np.zeros(nw, dtype=np.int64)
-    half_n = nw // 2
+    half_n = (nw + 1) // 2   # emcee: colours 0, 1, 0, 1, ... -> the first colour is the larger one of an odd ensemble
     for it in range(nsteps):
         step = first_step + it
         perm = split_permutation(seed, step, nw) if randomize_split else np.arange(nw)

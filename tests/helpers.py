@@ -59,7 +59,7 @@ class OracleBackend:
         self.fn = log_prob_fn
         self.X = np.array(coords, dtype=np.float64)
         self.nw, self.ndim = self.X.shape
-        self.n_half = self.nw // 2
+        self.n_half = (self.nw + 1) // 2   # slots per half-step: the larger colour of an odd ensemble
         self.LP = np.asarray(log_prob_fn(self.X), dtype=np.float64)
         self.seed, self.a = seed, a
         self._newlp = torch.zeros(self.n_half, dtype=torch.float64)
@@ -81,8 +81,11 @@ class OracleBackend:
         self.Q = partner - (partner - self.X[self.act]) * z[:, None]
         self.zl = (self.ndim - 1.) * np.log(z)
         self._newlp.fill_(float('nan'))  # a rank that forgets to fill its shard is caught by the NaN check
+        self.n_act = len(self.act)       # (one less than n_half in the second half-step of an odd ensemble)
+        self._newlp[self.n_act:] = -np.inf
 
     def evaluate(self, lo, hi):
+        hi = min(hi, self.n_act)
         if hi > lo:
             self._newlp[lo:hi] = self.torch.from_numpy(np.asarray(self.fn(self.Q[lo:hi]), dtype=np.float64))
 
@@ -93,7 +96,7 @@ class OracleBackend:
         return self.torch.empty(n, dtype=self.torch.float64)
 
     def accept(self, step, half):
-        new = self._newlp.numpy()
+        new = self._newlp.numpy()[:self.n_act]
         assert not np.any(np.isnan(new)), 'a shard of newlp was never filled'
         ok = self.zl + new - self.LP[self.act] > self.lnu
         self.X[self.act[ok]] = self.Q[ok]

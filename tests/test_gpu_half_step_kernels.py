@@ -1,0 +1,152 @@
+"""The three ways a single-GPU run can execute a half-step -- one workgroup per proposal that also accepts or rejects
+(k_solo), one workgroup per (proposal, part) (k_fused), separate proposal / likelihood launches -- must produce ONE
+chain, bit for bit, and that chain must be the oracle-driven one: odd ensembles, runs that cross the blocks in which the
+draw records are generated, runs that continue each other, a light curve edited in place."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from helpers import lc_dict, oracle_log_posterior, small_problem
+from lightcurve_fitting_amd import models as M
+from lightcurve_fitting_amd.engine import NativeSampler
+from lightcurve_fitting_amd.sampler import EnsembleSampler
+from oracle import lcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PRIORS = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+
+
+def _small(nwalkers, seed=1):
+    pb = small_problem()
+    lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
+    eng = M.ShockCooling(redshift=0.).engine_for(lc, priors=PRIORS)
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(seed).standard_normal((nwalkers, 5)))
+    return pb, eng, x0
+
+
+def _multiband(n_epochs=110, seed=77):
+    """Shared epochs, several chunks of points in two parts, R near its prior edge (some proposals are excluded)."""
+    rng = np.random.default_rng(seed)
+    epochs = np.sort(rng.uniform(0.4, 9., n_epochs))
+    t, names = np.repeat(epochs, 6), list(np.tile(list('UBVgri'), n_epochs))
+    bands = [O.band(n) for n in names]
+    truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    om = ('ShockCooling', O.ShockCoolingOracle(0.004))
+    ytrue = O.evaluate(om, t, bands, truth)
+    y, dy = ytrue * (1 + 0.05 * rng.standard_normal(len(t))), 0.05 * ytrue
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    pb = dict(model=om, orc=None, t=t, bands=bands, y=y, dy=dy, priors=[p.descriptor() for p in priors], truth=truth)
+    eng = M.ShockCooling(redshift=0.004).engine_for(lc_dict(t, names, y, dy), priors=priors)
+    return pb, eng
+
+
+def _run(eng, nwalkers, seed, x0, nsteps, kernel, split='random'):
+    s = NativeSampler(eng, nwalkers, seed)
+    used = s.set_half_step_kernel(kernel)
+    s.set_state(x0)
+    s.run(0, nsteps, split, True)
+    chain, lp = s.get_chain()
+    return used, chain, lp, s.naccepted(), s
+
+
+@pytest.mark.parametrize('nwalkers', [40, 41])
+def test_three_kernels_one_chain(nwalkers):
+    pb, eng = _multiband()
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(3).standard_normal((nwalkers, 5)))
+    runs = {k: _run(eng, nwalkers, 2024, x0, 9, k) for k in ('auto', 'fused', 'phases')}
+    assert [runs[k][0] for k in ('auto', 'fused', 'phases')] == ['solo', 'fused', 'phases']
+    for k in ('fused', 'phases'):
+        assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][2], runs[k][2])
+        assert np.array_equal(runs['auto'][3], runs[k][3])
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 9, 2024)
+    assert relerr(runs['auto'][1], ref) < 1e-9 and relerr(runs['auto'][2], ref_lp) < 1e-9
+    assert np.array_equal(runs['auto'][3], ref_acc) and 0 < ref_acc.sum() < 9 * nwalkers
+
+
+@pytest.mark.parametrize('kernel', ['auto', 'fused', 'phases'])
+@pytest.mark.parametrize('nwalkers,randomize', [(11, True), (13, False), (27, True)])
+def test_odd_ensembles_follow_emcee_split(nwalkers, randomize, kernel):
+    """An odd ensemble: the larger colour (ceil(n / 2) walkers) moves first against the smaller one, as in emcee's
+    red-blue move; the last slot of every second half-step stays empty."""
+    pb, eng, x0 = _small(nwalkers, seed=nwalkers)
+    _, chain, lp, acc, _ = _run(eng, nwalkers, 4242, x0, 7, kernel, 'random' if randomize else 'identity')
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 7, 4242, randomize_split=randomize)
+    assert relerr(chain, ref) < 1e-9 and relerr(lp, ref_lp) < 1e-9 and np.array_equal(acc, ref_acc)
+
+
+def test_long_run_crosses_draw_blocks():
+    """300 steps = a short first block of draw records, one full block of 256 and a remainder: nothing may change at
+    the seams, for the kernel that needs no slot bookkeeping and for the ones that carry it across blocks."""
+    pb, eng, x0 = _small(16, seed=8)
+    runs = {k: _run(eng, 16, 99, x0, 300, k) for k in ('auto', 'fused', 'phases')}
+    for k in ('fused', 'phases'):
+        assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][3], runs[k][3])
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 300, 99)
+    assert relerr(runs['auto'][1], ref) < 1e-8 and np.array_equal(runs['auto'][3], ref_acc)
+
+
+@pytest.mark.parametrize('kernel', ['auto', 'fused'])
+def test_runs_that_continue_each_other(kernel):
+    """10 + 10 + 5 steps (the second run adopts the draw records the first one left behind for it; the third changes
+    the colouring, so what the second one left is discarded) == the same 25 steps of the oracle."""
+    pb, eng, x0 = _small(24, seed=5)
+    s = NativeSampler(eng, 24, 606)
+    s.set_half_step_kernel(kernel)
+    s.set_state(x0)
+    chains = []
+    for first, n, split in ((0, 10, 'random'), (10, 10, 'random'), (20, 5, 'identity')):
+        s.run(first, n, split, True)
+        chains.append(s.get_chain()[0])
+    fn = oracle_log_posterior(pb)
+    a, a_lp, _ = O.stretch_move_run(fn, x0, 20, 606)
+    b, _, _ = O.stretch_move_run(fn, a[-1], 5, 606, log_prob0=a_lp[-1], randomize_split=False, first_step=20)
+    assert relerr(np.concatenate(chains), np.concatenate([a, b])) < 1e-9
+    x, lp = s.get_state()
+    assert np.array_equal(x, chains[-1][-1])
+
+
+def test_state_calls_between_and_after_runs():
+    """get_state / naccepted are served from the snapshot a run leaves in host memory; set_state and further runs must
+    refresh it."""
+    pb, eng, x0 = _small(20, seed=2)
+    s = NativeSampler(eng, 20, 1)
+    s.set_state(x0)
+    x, lp = s.get_state()
+    assert np.array_equal(x, x0) and relerr(lp, oracle_log_posterior(pb)(x0)) < 1e-11
+    s.run(0, 4, 'random', True)
+    x1, lp1 = s.get_state()
+    assert np.array_equal(x1, s.get_chain()[0][-1]) and np.array_equal(lp1, s.get_chain()[1][-1])
+    acc1 = s.naccepted()
+    s.run(4, 3, 'random', False)
+    x2, _ = s.get_state()
+    assert not np.array_equal(x1, x2) and np.all(s.naccepted() >= acc1)
+    s.set_state(x0)
+    assert np.array_equal(s.get_state()[0], x0) and not s.naccepted().any()
+
+
+def test_engine_follows_the_light_curve_content():
+    """Model.log_likelihood reads the light curve on every call (reference models.py:116-119): editing a column in
+    place, or a new light-curve object, must never be answered from an engine built for other photometry."""
+    pb = small_problem()
+    lc = lc_dict(pb['t'], pb['names'], pb['y'], pb['dy'])
+    m = M.ShockCooling(redshift=0.)
+    P = pb['truth'] * (1 + 0.02 * np.random.default_rng(0).standard_normal((6, 5)))
+    before = m.log_likelihood(lc, P)
+    eng = m.engine_for(lc)
+    assert m.engine_for(lc) is eng                       # unchanged content: the same engine
+    lc['lum'][:] = lc['lum'] * 1.05                      # in-place edit (what calcAbsMag / calcLum do on a refit)
+    after = m.log_likelihood(lc, P)
+    assert np.all(before != after)
+    om = ('ShockCooling', O.ShockCoolingOracle(0.))
+    want = O.log_likelihood(om, pb['t'], pb['bands'], lc['lum'], lc['dlum'], P.T)
+    assert relerr(after, want) < 1e-11
+    # an engine that left the cache stays usable by whoever holds it (samplers, closures)
+    s = EnsembleSampler(12, 5, eng, seed=3)
+    for k in range(m.max_bound_engines + 2):
+        other = lc_dict(pb['t'], pb['names'], pb['y'] * (1 + 0.01 * (k + 1)), pb['dy'])
+        m.log_likelihood(other, P)
+    assert all(b.engine is not eng for b in m._bound)
+    s.run_mcmc(P[:1] * (1 + 0.01 * np.random.default_rng(1).standard_normal((12, 5))), 3)
+    assert np.all(np.isfinite(s.get_log_prob()))
+    assert relerr(eng.log_likelihood(P), before) == 0.

@@ -68,7 +68,7 @@ def test_posterior_statistics_and_determinism():
 
 def test_sampler_input_validation():
     pb, lc, m, eng, x0 = _setup(32)
-    with pytest.raises(ValueError, match='nwalkers'):
+    with pytest.raises(ValueError, match='fewer walkers than twice'):
         EnsembleSampler(8, 5, eng)
     with pytest.raises(ValueError, match='ndim'):
         EnsembleSampler(32, 4, eng)
