@@ -1,20 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: walker-steps/s of the ensemble sampler on BASELINE.json configs[1]
-(ShockCooling, 1024 walkers per GPU, 500 synthetic epochs x {U,B,V,g,r,i} = 3000 points, float64).
+"""Benchmarks of the MI355X light-curve likelihood engine.  One JSON line on stdout (rank 0).
 
-A "step" is one ensemble step: every walker gets one stretch-move proposal, i.e. one log-posterior evaluation of
-all 3000 points (two half-steps of n_walkers/2 proposals each).  With N GPUs the ensemble has 1024*N walkers (weak
-scaling): proposals and accept/reject are replicated, each rank evaluates its shard of the active half and one
-all-gather of the new log-probabilities per half-step (RCCL) makes the ranks agree.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mcmc|companion|population|sed]
 
-Prints ONE JSON line on rank 0 (see the driver contract).  Extra keys:
-  roofline     -- the dominant kernel (per-point likelihood kernel) against the FP64 vector-ALU ceiling, measured live
-                  with HIP events; `hbm` carries the achieved HBM figures (the path is not memory-bound)
-  cpu_baseline -- the CPU oracle in reference-shaped mode (one call per walker, Python loop over points) on 1 core
+Headline (`--workload mcmc`, the default): walker-steps/s of the ensemble sampler on BASELINE.json configs[1]
+(ShockCooling, 1024 walkers per GPU, 500 synthetic epochs x {U,B,V,g,r,i} = 3000 points, float64).  A "step" is one
+ensemble step: every walker gets one stretch-move proposal, i.e. one log-posterior evaluation of all 3000 points (two
+half-steps of n_walkers/2 proposals each).
+
+`--gpus N` with N > 1 and no launcher environment (no WORLD_SIZE): this process starts N fresh worker processes -- one
+rank per GPU, before it makes any GPU call itself (it never imports torch) -- and returns their worst exit code.  Under
+a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) the ranks are taken from the
+environment; a WORLD_SIZE that differs from --gpus is an error, never a silently smaller run.  With N GPUs the walkers
+of one ensemble are sharded: proposals and accept/reject are replicated, each rank evaluates its shard of the active
+half, and one all-gather per half-step (RCCL) makes the ranks agree (`scaling`: weak = 1024 walkers per GPU for the
+headline, strong = the 4096 walkers of configs[2] over the N GPUs for `--workload companion`).
+
+Extra objects of the line:
+  roofline      the dominant kernel against the FP64 vector-ALU issue rate.  `achieved` = vector-ALU lane-instructions
+                of the band-sum loop THE SHIPPED ALGORITHM executes (samples it walks x the loop's instruction count
+                from the ISA, tools/isa_count.py) / live kernel time (HIP events on the kernel's stream): a lower bound
+                of what the kernel issues, so `frac` <= 1 by construction.  `executed_pmc` (all vector-ALU
+                instructions, SQ_INSTS_VALU) and `traffic` come from rocprofv3 --pmc passes and are included only when
+                the committed summary was collected from the kernel sources of this tree (hash recorded in the file).
+                `algorithmic_speedup` = SURVEY 8d's instruction count of the reference's algorithm / the time.
+  cpu_baseline  the CPU oracle in reference-shaped mode (one call per walker, Python loop over points) on 1 core
+  collective    (N > 1) which driver ran the all-gather, the rank count the RCCL communicator itself reports, and the
+                measured time of one per-half-step all-gather
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,16 +47,274 @@ N_EPOCHS = 500
 BANDS = ['U', 'B', 'V', 'g', 'r', 'i']
 TRUTH = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
 SEED = 20241024
+COMPANION_BANDS = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'unfilt.']
+COMPANION_TRUTH = np.array([57001., 0.5, 1.2, 57018., 1.05, 0.95, 0.9, 0.6])
+COMPANION_WALKERS = 4096          # BASELINE configs[2]
 
-# algorithmic work of ONE log-likelihood evaluation at this config
+# FP64 VALU instructions per Planck sample / per point of the REFERENCE's algorithm
+ALG_INSTR_PER_SAMPLE, ALG_INSTR_PER_POINT = 34, 68
 ALG_SAMPLES = N_EPOCHS * (13 + 11 + 15 + 89 + 75 + 89)        # Planck samples the reference evaluates: 146000
 ALG_POINTS = N_EPOCHS * len(BANDS)
-ALG_INSTR = 34 * ALG_SAMPLES + 68 * ALG_POINTS                 # FP64 VALU instructions (1/expm1 = 32, +mul, +fma)
+ALG_INSTR = ALG_INSTR_PER_SAMPLE * ALG_SAMPLES + ALG_INSTR_PER_POINT * ALG_POINTS
 ALG_BYTES = 8 * (5 + 1)                                        # HBM bytes per walker-step: parameters in, lnL out
 PEAK_FP64_TINSTR = 256 * 64 * 2.4e9 / 1e12                     # 39.3 T FP64 lane-instructions/s (= 78.6 TFLOP/s FMA)
+PEAK_FP32_TINSTR = 2 * PEAK_FP64_TINSTR                        # 157.3 TFLOP/s FMA
 PEAK_HBM_GBS = 8000.
+# Vector-ALU instructions per quad of samples in the shipped band-sum loop (58 FP64 + 23 other: exp via table and
+# degree-4 polynomial, four samples sharing one division), counted in the ISA of k_solo<5,1,true,2> by
+# tools/isa_count.py; the float32 SED loop (k_sed<1>): 80 per quad
+VALU_PER_QUAD_F64 = 81
+VALU_PER_QUAD_F32 = 80
 
 
+# =====================================================================================================================
+# launching
+# =====================================================================================================================
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population', 'companion'],
+                    help="'mcmc' (default) = the headline configs[1] line; the others print their own line")
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000,
+                    help='ensemble steps in the timed region (BASELINE configs[1] runs 2000)')
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default=None,
+                    help='mcmc: weak (1024 walkers per GPU, default) or strong (1024 in all); companion: strong (the '
+                         '4096 walkers of configs[2] over the GPUs, default) or weak (512 per GPU)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--variant', type=int, default=2,
+                    help='band sum: 2 = Gauss-compressed tables (default), 1 = the full tables, 0 = libm')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='only start the ranks, let them find each other (gloo) and print what they saw')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Start n worker processes of this script (fresh interpreters: this parent has not touched the GPU and never
+    does) and return the worst exit code.  Rank 0 prints the JSON line."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), LCF_BENCH_SPAWNED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def init_distributed(args):
+    """(torch.distributed or None, rank, world, local_rank).  Dry runs on a single-GPU box: LCF_BENCH_ONE_DEVICE=1 maps
+    every rank to cuda:0 and uses gloo (RCCL refuses two ranks on one device); the numbers of such a run are
+    meaningless, the code path is the real one."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
+    import torch
+    if world == 1:
+        torch.cuda.set_device(0)
+        return None, 0, 1, 0
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    return dist, rank, world, local_rank
+
+
+def launch_check(args):
+    """No GPU work: every rank joins a gloo group and reports; rank 0 prints what the group looks like."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
+    seen = [rank]
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        seen = sorted(int(g.item()) for g in got)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_seen': seen,
+                          'spawned_by_bench': os.environ.get('LCF_BENCH_SPAWNED') == '1'}), flush=True)
+
+
+def max_over_ranks(dist, elapsed):
+    if dist is None:
+        return elapsed
+    import torch
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item())
+
+
+def timed_run(sampler, dist, warmup, steps, x0):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the maximum
+    over the ranks."""
+    import torch
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sampler.run_mcmc(x0, warmup, store=False)         # untimed warm-up (also allocates everything)
+    barrier()
+    t0 = time.perf_counter()
+    sampler.run_mcmc(None, steps, store=False)        # returns after the device has finished
+    barrier()
+    return max_over_ranks(dist, time.perf_counter() - t0)
+
+
+def collective_info(sampler, dist, world):
+    """Which driver a multi-rank run used, the communicator's own rank count, one all-gather's time."""
+    if dist is None:
+        return None
+    comm = sampler._native_comm()
+    n_half = (sampler.nwalkers + 1) // 2
+    rows = sampler._native.rows_ptr()[1]
+    if comm is not None:
+        n, r = comm.count()
+        return {'driver': 'native: lcf_sampler_run_sharded, ncclAllGather enqueued per half-step',
+                'rccl_comm_ranks': n, 'allgather_us': 1e3 * comm.time_allgather(sampler._native, 200),
+                'payload_bytes_per_rank': 8 * rows * n_half // world}
+    import torch
+    backend = dist.get_backend()
+    dev = 'cuda' if backend == 'nccl' else 'cpu'
+    w = (n_half + world - 1) // world
+    buf = torch.zeros(w * world, rows, dtype=torch.float64, device=dev)
+    r = dist.get_rank()
+    for _ in range(5):
+        dist.all_gather_into_tensor(buf, buf[r * w:(r + 1) * w].clone())
+    if dev == 'cuda':
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        dist.all_gather_into_tensor(buf, buf[r * w:(r + 1) * w].clone())
+    if dev == 'cuda':
+        torch.cuda.synchronize()
+    return {'driver': f'torch.distributed ({backend}) collectives driven from Python per half-step',
+            'rccl_comm_ranks': None, 'group_ranks': dist.get_world_size(),
+            'allgather_us': 1e4 * (time.perf_counter() - t0), 'payload_bytes_per_rank': 8 * rows * w}
+
+
+# =====================================================================================================================
+# roofline
+# =====================================================================================================================
+def kernel_source_sha():
+    """Hash of everything the device code is compiled from: a PMC summary applies to this tree iff it carries it."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'lightcurve_fitting_amd', 'csrc')
+    for path in sorted([os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h'))] +
+                       [os.path.join(ROOT, 'include', 'lcf.h')]):
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()
+
+
+def committed_pmc(tag):
+    """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc_<tag>.json, written
+    by tools/collect_profiles.sh; counters cannot be read from inside this process) -- or the reason they are not used."""
+    path = os.path.join(ROOT, 'profiles', f'r02_pmc_{tag}.json')
+    try:
+        doc = json.load(open(path))
+    except Exception as exc:  # noqa: BLE001
+        return None, f'no PMC summary ({type(exc).__name__})'
+    if doc.get('kernel_source_sha256') != kernel_source_sha():
+        return None, ('profiles/' + os.path.basename(path) + ' was collected from other kernel sources (commit '
+                      + str(doc.get('collected_at_commit')) + '): not used')
+    return doc, None
+
+
+def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_quad, peak, alg_instr_per_eval,
+                   alg_bytes_per_eval, pmc_tag, waves_per_launch=None):
+    """`achieved` / `frac`: lane-instructions of the band-sum loop the shipped algorithm executes per second, against
+    the vector-ALU issue peak -- a lower bound of what the kernel issues."""
+    sec = kern_ms * 1e-3
+    shipped = evals_per_launch * quads_per_eval * valu_per_quad
+    achieved = shipped / sec / 1e12
+    out = {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'Tinstr/s', 'frac': achieved / peak,
+           'kernel': kernel, 'kernel_ms': kern_ms, 'evaluations_per_launch': evals_per_launch,
+           'basis': f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x '
+                    f'{valu_per_quad} vector-ALU instructions per quad (ISA count, tools/isa_count.py): the band-sum loop '
+                    'only, a lower bound of the instructions issued',
+           'algorithmic_speedup': evals_per_launch * alg_instr_per_eval / sec / 1e12 / peak,
+           'algorithmic_speedup_note': "SURVEY 8d's instruction count of the reference's algorithm per second / the "
+                                       'issue peak: exceeds 1 where the shipped algorithm needs fewer instructions '
+                                       '(not a utilisation)',
+           'hbm': {'achieved': evals_per_launch * alg_bytes_per_eval / sec / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                   'frac': evals_per_launch * alg_bytes_per_eval / sec / 1e9 / PEAK_HBM_GBS,
+                   'algorithmic_bytes_per_evaluation': alg_bytes_per_eval}}
+    doc, why = committed_pmc(pmc_tag)
+    if doc is None:
+        out['traffic'] = None
+        out['executed_pmc'] = None
+        out['pmc_note'] = why
+        return out
+    c = {k: v['mean_per_launch'] for k, v in doc['counters'].items()}
+    # FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads prescribes (MI355X_MICROARCH.md,
+    # HBM section); both counters are in KiB
+    out['traffic'] = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024. if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c else None
+    out['traffic_unit'] = 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)'
+    out['executed_pmc'] = None
+    if 'SQ_INSTS_VALU' in c and 'SQ_WAVES' in c:
+        waves = waves_per_launch or c['SQ_WAVES']
+        valu_launch = c['SQ_INSTS_VALU'] * waves / c['SQ_WAVES']   # (the SQ counters may cover a subset of the waves)
+        real = 64. * valu_launch / sec / 1e12
+        ex = {'achieved': real, 'peak': peak, 'unit': 'Tinstr/s', 'frac': real / peak,
+              'valu_instr_per_wave': c['SQ_INSTS_VALU'] / c['SQ_WAVES'],
+              'note': 'ALL vector-ALU lane-instructions issued (SQ_INSTS_VALU x 64 per launch) / live kernel time'}
+        if 'SQ_ACTIVE_INST_VALU' in c and 'GRBM_GUI_ACTIVE' in c:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs
+            simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / waves)
+            ex['valu_busy'] = 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles
+        out['executed_pmc'] = ex
+    out['pmc_provenance'] = {'file': f'profiles/r02_pmc_{pmc_tag}.json', 'collected_at_commit': doc.get('collected_at_commit'),
+                             'kernel_source_sha256': doc.get('kernel_source_sha256')[:16], 'kernel': doc.get('kernel')}
+    return out
+
+
+def quads_per_evaluation(engine, truth):
+    """Quads of samples one likelihood evaluation walks at the parameters `truth` (the table level is chosen per point
+    from its temperature)."""
+    T, _ = engine.temperature_radius(np.asarray(truth, dtype=float))
+    compressed = getattr(engine, '_variant', 2) == 2
+    return float(np.sum(engine.tables.samples_at(engine.filt_idx, T[0], compressed)) / 4.)
+
+
+def half_step_kernel_ms(engine, nwalkers, x0, seed, reps=1000):
+    """Average duration of the half-step kernel of a single-GPU run (one launch = one half-step = nwalkers/2 proposals:
+    proposal + thermal states + likelihood + accept test), from HIP events on the engine's stream around `reps` steps =
+    2*reps back-to-back launches (the draw-record kernels in between: 40 us per 256 steps)."""
+    from lightcurve_fitting_amd.engine import NativeSampler
+    s = NativeSampler(engine, nwalkers, seed)
+    used = s.set_half_step_kernel('auto')
+    s.set_state(x0[:nwalkers])
+    s.run(0, 50, 'random', False)
+    s.run(50, reps, 'random', False)
+    ms = s.last_run_ms() / (2 * reps)
+    s.close()
+    return ms, used
+
+
+# =====================================================================================================================
+# workloads
+# =====================================================================================================================
 def build_problem(device):
     from lightcurve_fitting_amd import models as M
     rng = np.random.default_rng(SEED)
@@ -61,64 +338,6 @@ def initial_walkers(n):
     return rng.uniform(lo, hi, (n, 5))
 
 
-def committed_pmc(variant):
-    """HBM traffic and VALU utilisation of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_k_fused_v<variant>.json, collected by tools/collect_profiles.sh; counters cannot be read from
-    inside this process).  FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads
-    prescribes (MI355X_MICROARCH.md, HBM section); both are in KiB per launch of 512 proposals."""
-    path = os.path.join(ROOT, 'profiles', f'r01_pmc_k_fused_v{variant}.json')
-    try:
-        c = {k: v['mean_per_launch'] for k, v in json.load(open(path)).items()}
-        traffic = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.
-        # SQ_ACTIVE_INST_VALU counts quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; the SQ counters cover
-        # SQ_WAVES of the launched waves (512 proposals x 2 workgroups x 4 waves)
-        simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / (512 * 2 * 4))
-        return traffic, 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles, c['SQ_INSTS_VALU'] / c['SQ_WAVES'], \
-            c['SQ_INSTS_VALU'] * (512 * 2 * 4) / c['SQ_WAVES']
-    except Exception:
-        return None, None, None, None
-
-
-def fused_kernel_ms(engine, x0, reps=1000):
-    """Average duration of the dominant kernel, k_fused (one launch = one half-step of a 1024-walker ensemble =
-    512 proposals: commit + draw + thermal states + likelihood), from HIP events on the engine's stream around
-    `reps` steps = 2*reps back-to-back launches (plus one trailing 5-us commit launch, i.e. < 0.03 us per launch)."""
-    from lightcurve_fitting_amd.engine import NativeSampler
-    s = NativeSampler(engine, WALKERS_PER_GPU, SEED + 7)
-    s.set_state(x0[:WALKERS_PER_GPU])
-    s.run(0, 50, 'random', False)
-    s.run(50, reps, 'random', False)
-    ms = s.last_run_ms() / (2 * reps)
-    s.close()
-    return ms
-
-
-def roofline_entry(engine, x0, shard, variant):
-    """Dominant kernel (HIP events on the engine's stream, 200 back-to-back launches) against the FP64 VALU ceiling
-    by the ALGORITHMIC instruction count of SURVEY 8d."""
-    engine.set_variant(variant)
-    shard = WALKERS_PER_GPU // 2
-    kern_ms = fused_kernel_ms(engine, x0)
-    evals_per_s = shard / (kern_ms * 1e-3)
-    achieved = evals_per_s * ALG_INSTR / 1e12
-    hbm_gbs = evals_per_s * ALG_BYTES / 1e9
-    traffic, valu_util, valu_per_wave, valu_per_launch = committed_pmc(variant)
-    # vector-ALU instructions the kernel REALLY executes (PMC count per launch, 64 lanes each) over the live kernel time
-    real = None if valu_per_launch is None else 64. * valu_per_launch / (kern_ms * 1e-3) / 1e12
-    return {'bound': 'fp64-valu', 'achieved': achieved, 'peak': PEAK_FP64_TINSTR, 'unit': 'Tinstr/s',
-            'frac': achieved / PEAK_FP64_TINSTR, 'traffic': traffic,
-            'traffic_unit': 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)',
-            'valu_utilisation_pmc': valu_util, 'valu_instr_per_wave_pmc': valu_per_wave,
-            'executed': None if real is None else {'achieved': real, 'peak': PEAK_FP64_TINSTR, 'unit': 'Tinstr/s',
-                                                   'frac': real / PEAK_FP64_TINSTR,
-                                                   'note': 'vector-ALU lane-instructions actually issued (all types), '
-                                                           'PMC count per launch / live kernel time'},
-            'kernel': 'k_fused<5,1,true> (a whole half-step: commit + proposal + thermal states + likelihood)',
-            'band_sum_variant': variant, 'kernel_ms': kern_ms, 'walkers_per_launch': shard,
-            'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
-                    'algorithmic_bytes_per_walker_step': ALG_BYTES}}
-
-
 def cpu_baseline(lc, budget_s=12., max_evals=128):
     """Reference-shaped CPU evaluation (per-walker call, per-point Python loop, K-sample trapezoid) on one core."""
     from oracle import lcf_oracle as O   # checker only: never on the product path
@@ -138,188 +357,16 @@ def cpu_baseline(lc, budget_s=12., max_evals=128):
     O.log_likelihood(model, lc['MJD'], bands, lc['lum'], lc['dlum'], Pv.T)
     dtv = time.perf_counter() - tv
     return {'value': n / dt, 'unit': 'walker-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} per-walker log-likelihood evaluations of the same 3000-point light curve '
-                      f'(oracle in reference-shaped mode: Python loop over points, {ALG_SAMPLES} Planck samples each), '
+            'sample': f'{n} per-walker log-likelihood evaluations of the same {len(bands)}-point light curve '
+                      f'(oracle in reference-shaped mode: Python loop over points), '
                       f'{dt:.1f} s on 1 of {os.cpu_count()} host cores',
             'ideal_pool_value': n / dt * (os.cpu_count() or 1), 'host_cores': os.cpu_count(),
             'vectorised_numpy_value': len(Pv) / dtv}
 
 
-def init_distributed():
-    """(torch.distributed or None, rank, world, local_rank) from the launcher's environment, one process per GPU over
-    RCCL.  Dry runs on a single-GPU box: LCF_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and uses gloo (RCCL refuses
-    two ranks on one device); the numbers of such a run are meaningless, the code path is the real one."""
-    import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world == 1:
-        torch.cuda.set_device(0)
-        return None, 0, 1, 0
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1':
-        local_rank = 0
-        torch.cuda.set_device(0)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    return dist, rank, world, local_rank
-
-
-def max_over_ranks(dist, elapsed):
-    if dist is None:
-        return elapsed
-    import torch
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return float(tmax.item())
-
-
-def run_sed(args):
-    """BASELINE configs[3]: per-epoch blackbody SED grid, 10 000 epochs x 6 filters (UBVgri) x 128 (T, R) candidates,
-    float32 arithmetic with the float64 kernel as the error reference.  Extra workload: prints its own JSON line."""
-    from lightcurve_fitting_amd import bolometric as B
-    from lightcurve_fitting_amd import models as M
-    rng = np.random.default_rng(SEED + 4)
-    n_ep, n_c = 10000, 128
-    Tt, Rt = rng.uniform(5., 50., n_ep), 10 ** rng.uniform(-1., 2., n_ep)
-    ytrue = M.blackbody_to_filters(BANDS, Tt, Rt)                     # (6, n_ep) on the GPU
-    y = ytrue.T * (1. + 0.03 * rng.standard_normal((n_ep, 6)))
-    epochs = [(BANDS, y[e], 0.03 * ytrue[:, e]) for e in range(n_ep)]
-    cand = np.stack([rng.uniform(1., 100., (n_ep, n_c)), 10 ** rng.uniform(-2., 3., (n_ep, n_c))], axis=-1)
-    like = B.SpectrumLikelihood(epochs, z=0.)
-    out = {}
-    for prec in ('f32', 'f64'):
-        res = like(cand, precision=prec)                              # warm-up
-        ms = []
-        for _ in range(max(3, args.steps // 20)):
-            res = like(cand, precision=prec)
-            ms.append(like.engine.last_kernel_ms)
-        out[prec] = (res, float(np.median(ms)))
-    samples = float(np.sum(like.samples_per_candidate)) * n_c          # real (zero-weight rows dropped)
-    alg_samples = n_ep * n_c * (13 + 11 + 15 + 89 + 75 + 89)
-    err = np.abs(out['f32'][0] - out['f64'][0]) / np.abs(out['f64'][0])
-    print(json.dumps({
-        'metric': 'SED candidate evaluations/sec', 'value': n_ep * n_c / (out['f32'][1] * 1e-3), 'unit': 'candidates/s',
-        'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic', 'higher_is_better': True, 'vs_baseline': None,
-        'config': {'workload': 'BASELINE configs[3]: 10000 epochs x 6 filters (UBVgri) x 128 (T,R) candidates',
-                   'planck_samples_per_launch': alg_samples},
-        'kernel_ms_f32': out['f32'][1], 'kernel_ms_f64': out['f64'][1],
-        'planck_samples_per_s_f32': alg_samples / (out['f32'][1] * 1e-3),
-        'planck_samples_per_s_f64': alg_samples / (out['f64'][1] * 1e-3),
-        'real_samples_per_launch': samples,
-        'f32_vs_f64_lnL_relative_error': {'max': float(err.max()), 'median': float(np.median(err))}}), flush=True)
-
-
-def run_companion(args):
-    """BASELINE configs[2]: CompanionShocking (Kasen shock + SiFTO template), 8 filters x 1000 epochs = 8000 points,
-    512 walkers per GPU in one ensemble (4096 on 8 GPUs), walker-sharded with one all-gather per half-step.
-    Extra workload: prints its own JSON line."""
-    import torch
-    from lightcurve_fitting_amd import models as M
-    from lightcurve_fitting_amd.sampler import EnsembleSampler
-    dist, rank, world, local_rank = init_distributed()
-    rng = np.random.default_rng(SEED + 1)
-    bands = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'unfilt.']
-    epochs = np.sort(rng.uniform(57001., 57060., 1000))
-    t, names = np.repeat(epochs, 8), list(np.tile(bands, 1000))
-    q = np.array([57001., 0.5, 1.2, 57018., 1.05, 0.95, 0.9, 0.6])
-    peak = {'U': 2.1e20, 'B': 2.6e20, 'V': 2.4e20, 'g': 2.5e20, 'r': 2.2e20, 'i': 1.7e20, 'DLT40': 2.2e20,
-            'unfilt.': 2.2e20}
-    lum0 = np.array([peak[n] for n in names]) * np.exp(-0.5 * ((t - 57018.) / 12.) ** 2)
-    model = M.CompanionShocking({'MJD': t, 'filter': names, 'lum': lum0, 'dlum': 0.05 * lum0}, redshift=0.003)
-    model.device = local_rank
-    ytrue = model(t, names, *q)
-    lc = {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * rng.standard_normal(len(t))),
-          'dlum': 0.05 * np.maximum(ytrue, 1e17)}
-    priors = [M.UniformPrior(56990., 57010.), M.UniformPrior(0., 10.), M.UniformPrior(0., 10.),
-              M.UniformPrior(57005., 57030.), M.UniformPrior(0.5, 2.)] + [M.UniformPrior(0., 3.)] * 3
-    nw = 512 * world
-    sampler = EnsembleSampler(nw, 8, model.engine_for(lc, priors=priors), seed=SEED)
-    x0 = q * (1 + 0.01 * np.random.default_rng(SEED + 2).standard_normal((nw, 8)))
-    x0[:, [0, 3]] = q[[0, 3]] + 0.3 * np.random.default_rng(SEED + 3).standard_normal((nw, 2))
-    sampler.run_mcmc(x0, args.warmup, store=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    sampler.run_mcmc(None, args.steps, store=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, elapsed)
-    if rank == 0:
-        print(json.dumps({'metric': 'walker-steps/sec (emcee ensemble)', 'value': nw * args.steps / elapsed,
-                          'unit': 'walker-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-                          'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-                          'acceptance_fraction': float(sampler.acceptance_fraction.mean()),
-                          'config': {'workload': 'BASELINE configs[2]: CompanionShocking + SiFTO template, 512 walkers '
-                                                 'per GPU, 8 filters x 1000 epochs = 8000 points, float64',
-                                     'walkers': nw, 'points': 8000}}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
-
-
-def run_population(args):
-    """BASELINE configs[4]: population mode -- independent synthetic transients (config-2-like, 100 epochs x 6 filters
-    = 600 points, own truth drawn +-20 %), 512 walkers each, transients partitioned over the GPUs (no communication).
-    32 transients per GPU.  Extra workload: prints its own JSON line."""
-    import torch
-    from lightcurve_fitting_amd import models as M
-    from lightcurve_fitting_amd.sampler import PopulationSampler
-    dist, rank, world, local_rank = init_distributed()
-    n_tr, nw = 32 * world, 512
-    rng = np.random.default_rng(SEED + 5)
-    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
-    problems, x0 = [], {}
-    for k in range(n_tr):
-        truth = TRUTH * rng.uniform(0.8, 1.2, 5)
-        epochs = np.sort(rng.uniform(0.5, 10., 100))
-        t, names = np.repeat(epochs, 6), list(np.tile(BANDS, 100))
-        model = M.ShockCooling(redshift=0.)
-        model.device = local_rank
-        noise = rng.standard_normal(600)
-        walkers = truth * rng.uniform(0.9, 1.1, (nw, 5))
-        if k * world // n_tr == rank:  # only this rank's share is built on the device
-            ytrue = model(t, names, *truth)
-            problems.append((model, {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * noise), 'dlum': 0.05 * ytrue},
-                             priors))
-        else:
-            problems.append((model, None, priors))
-        x0[k] = walkers
-    pop = PopulationSampler(problems, nw, seed=SEED, device=local_rank)
-    pop.run_mcmc(x0, args.warmup, store=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    pop.run_mcmc(None, args.steps, store=False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, elapsed)
-    if rank == 0:
-        print(json.dumps({'metric': 'walker-steps/sec (population of independent ensembles)',
-                          'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
-                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-                          'data': 'synthetic',
-                          'config': {'workload': 'BASELINE configs[4]: population mode, 32 transients per GPU x 512 '
-                                                 'walkers, 600 points each (100 epochs x UBVgri)',
-                                     'transients': n_tr, 'walkers_per_transient': nw, 'points': 600}}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
-
-
 def cpu_baseline_c(lc, budget_s=8.):
     """The same evaluation through the plain-C oracle (oracle/lcf_oracle_c.c, gcc -O2, OpenMP over walkers): what an
     optimised CPU port reaches, on the host cores a 1-GPU slot owns.  Reported next to the reference-shaped figure."""
-    import subprocess
     from oracle import lcf_oracle as O
     so = os.path.join(ROOT, 'oracle', 'liblcf_oracle.so')
     if not os.path.exists(so):
@@ -339,89 +386,45 @@ def cpu_baseline_c(lc, budget_s=8.):
                       f'{dt:.1f} s on {threads} threads'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--workload', default='mcmc', choices=['mcmc', 'sed', 'population', 'companion'],
-                    help="'mcmc' (default) = the headline configs[1] line; 'sed' = configs[3] extra line")
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000,
-                    help='ensemble steps in the timed region (BASELINE configs[1] runs 2000)')
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--full-tables-reference', action='store_true',
-                    help='also time the dominant kernel over the full (uncompressed) band tables')
-    ap.add_argument('--variant', type=int, default=2,
-                    help='band sum: 2 = fused + Gauss-compressed tables (default), 1 = fused over the full tables, 0 = libm')
-    args = ap.parse_args()
-
-    if args.workload == 'sed':
-        import torch  # noqa: F401  (one HIP runtime per process: see engine.load_library)
-        return run_sed(args)
-    if args.workload == 'population':
-        return run_population(args)
-    if args.workload == 'companion':
-        return run_companion(args)
-    import torch
-    dist, rank, world, local_rank = init_distributed()
-    force_sharded = world == 1 and os.environ.get('LCF_BENCH_FORCE_SHARDED') == '1'
-    if force_sharded:  # diagnostic: exercise the multi-GPU code path (RCCL all-gather included) with one rank
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29517')
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    n_gpus = world
-
+def run_mcmc(args):
+    """BASELINE configs[1], the headline line."""
+    dist, rank, world, local_rank = init_distributed(args)
     from lightcurve_fitting_amd.sampler import EnsembleSampler
     model, lc, priors = build_problem(local_rank)
     engine = model.engine_for(lc, priors=priors)
     engine.set_variant(args.variant)
-    n_walkers = WALKERS_PER_GPU * n_gpus
-    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED, force_sharded=force_sharded)
+    engine._variant = args.variant
+    scaling = args.scaling or 'weak'
+    n_walkers = WALKERS_PER_GPU * (world if scaling == 'weak' else 1)
+    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED)
     x0 = initial_walkers(n_walkers)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    sampler.run_mcmc(x0, args.warmup, store=False)         # untimed warm-up (also allocates everything)
-    barrier()
-    t0 = time.perf_counter()
-    sampler.run_mcmc(None, args.steps, store=False)        # EXACTLY K steps; returns after the device has finished
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(dist, elapsed)
+    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = n_walkers * args.steps / elapsed
-
-    out = None
+    coll = collective_info(sampler, dist, world)
     if rank == 0:
-        # dominant kernel alone: the half-step batch of this rank's shard, for the variant used in the timed region
-        # and, for reference, for the full (uncompressed) band tables
-        shard = (n_walkers // 2) // n_gpus
-        roof = roofline_entry(engine, x0, shard, args.variant)
-        roof['note'] = ('FP64 vector-ALU lane-instructions, ALGORITHMIC count: 34 per Planck sample of the reference '
-                        "(146000 per evaluation) + 68 per point (SURVEY 8d); peak = 256 CU x 64 lanes x 2.4 GHz = 78.6 "
-                        'TFLOP/s FMA. frac exceeds 1 because the kernel needs far fewer instructions than the '
-                        'convention: ~19 per sample, and with the Gauss-compressed tables (variant 2) 8 samples '
-                        'reproduce the sum over up to 87 to 2e-14 above ~5 kK (12-16 below). '
-                        'valu_utilisation_pmc is the measured busy fraction of the vector ALU.')
-        roof_full = roofline_entry(engine, x0, shard, 1) if (args.full_tables_reference and args.variant != 1) else None
-        engine.set_variant(args.variant)
+        # dominant kernel alone, at this rank's share of a half-step when the run is sharded over the GPUs
+        per_rank = n_walkers // world
+        kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7)
+        quads = quads_per_evaluation(engine, TRUTH)
+        name = {'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
+                        '+ likelihood + accept test)',
+                'fused': 'k_fused<5,1,true>', 'phases': 'k_step + k_points'}[used]
+        roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, ALG_INSTR,
+                              ALG_BYTES, 'k_solo_mcmc', waves_per_launch=(per_rank // 2) * 8)
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
-            'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: ShockCooling (Sapir-Waxman n=1.5), 1024 walkers per GPU, '
                                    '500 synthetic epochs x 6 filters (UBVgri) = 3000 points, float64, '
                                    'device-resident stretch-move ensemble',
                        'walkers': n_walkers, 'points': ALG_POINTS, 'planck_samples_per_eval': ALG_SAMPLES,
-                       'parallelism': f'walker-sharded x{n_gpus}' if n_gpus > 1 else
-                       ('single GPU, multi-GPU code path forced' if force_sharded else 'single GPU')},
-            'roofline': roof, 'roofline_full_tables': roof_full,
-            'device_ms_per_step': sampler.last_run_ms / args.steps if n_gpus == 1 else None,
+                       'planck_samples_executed_per_eval': 4 * quads, 'band_sum_variant': args.variant,
+                       'parallelism': f'walker-sharded x{world}' if world > 1 else 'single GPU'},
+            'roofline': roof, 'collective': coll,
+            'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(lc)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
             try:
@@ -432,6 +435,246 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def build_companion(device):
+    from lightcurve_fitting_amd import models as M
+    rng = np.random.default_rng(SEED + 1)
+    epochs = np.sort(rng.uniform(57001., 57060., 1000))
+    t, names = np.repeat(epochs, 8), list(np.tile(COMPANION_BANDS, 1000))
+    peak = {'U': 2.1e20, 'B': 2.6e20, 'V': 2.4e20, 'g': 2.5e20, 'r': 2.2e20, 'i': 1.7e20, 'DLT40': 2.2e20,
+            'unfilt.': 2.2e20}
+    lum0 = np.array([peak[n] for n in names]) * np.exp(-0.5 * ((t - 57018.) / 12.) ** 2)
+    model = M.CompanionShocking({'MJD': t, 'filter': names, 'lum': lum0, 'dlum': 0.05 * lum0}, redshift=0.003)
+    model.device = device
+    ytrue = model(t, names, *COMPANION_TRUTH)
+    lc = {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * rng.standard_normal(len(t))),
+          'dlum': 0.05 * np.maximum(ytrue, 1e17)}
+    priors = [M.UniformPrior(56990., 57010.), M.UniformPrior(0., 10.), M.UniformPrior(0., 10.),
+              M.UniformPrior(57005., 57030.), M.UniformPrior(0.5, 2.)] + [M.UniformPrior(0., 3.)] * 3
+    return model, lc, priors, lum0
+
+
+def companion_walkers(nw):
+    q = COMPANION_TRUTH
+    x0 = q * (1 + 0.01 * np.random.default_rng(SEED + 2).standard_normal((nw, 8)))
+    x0[:, [0, 3]] = q[[0, 3]] + 0.3 * np.random.default_rng(SEED + 3).standard_normal((nw, 2))
+    return x0
+
+
+def cpu_baseline_companion(lc, lum0, budget_s=15.):
+    from oracle import lcf_oracle as O
+    bands = [O.band(n) for n in lc['filter']]
+    orc = O.CompanionShockingOracle(bands, lum0, z=0.003, variant=1)
+    P = companion_walkers(2048)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        O.log_likelihood(('CompanionShocking', orc), lc['MJD'], bands, lc['lum'], lc["dlum"], P[n % len(P)])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'walker-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} per-walker log-likelihood evaluations of the same 8000-point light curve (oracle: NumPy over '
+                      f'the points of a band, SciPy cubic spline per band), {dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+
+
+def run_companion(args):
+    """BASELINE configs[2]: CompanionShocking (Kasen shock + SiFTO template), 8 filters x 1000 epochs = 8000 points,
+    4096 walkers in one ensemble sharded over the GPUs with one all-gather per half-step (strong scaling, the
+    default: on one GPU all 4096 walkers), or 512 walkers per GPU (weak)."""
+    dist, rank, world, local_rank = init_distributed(args)
+    from lightcurve_fitting_amd.sampler import EnsembleSampler
+    model, lc, priors, lum0 = build_companion(local_rank)
+    scaling = args.scaling or 'strong'
+    nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
+    engine = model.engine_for(lc, priors=priors)
+    engine._variant = 2
+    sampler = EnsembleSampler(nw, 8, engine, seed=SEED)
+    x0 = companion_walkers(nw)
+    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
+    value = nw * args.steps / elapsed
+    coll = collective_info(sampler, dist, world)
+    if rank == 0:
+        per_rank = nw // world
+        kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7, reps=200)
+        quads = quads_per_evaluation(engine, COMPANION_TRUTH)
+        full = int(engine.samples_per_eval)
+        alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
+        name = {'solo': 'k_solo<8,1,true,4> (one 1024-thread workgroup per proposal)', 'fused': 'k_fused<8,1,true>',
+                'phases': 'k_step + k_points'}[used]
+        roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr,
+                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 16)
+        out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+               'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'acceptance_fraction': float(sampler.acceptance_fraction.mean()),
+               'config': {'workload': 'BASELINE configs[2]: CompanionShocking + SiFTO template, 4096 walkers, 8 filters '
+                                      'x 1000 epochs = 8000 points, float64, walkers sharded over the GPUs',
+                          'walkers': nw, 'points': 8000, 'planck_samples_per_eval': full,
+                          'planck_samples_executed_per_eval': 4 * quads},
+               'roofline': roof, 'collective': coll,
+               'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_companion(lc, lum0)
+            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_population(args):
+    """BASELINE configs[4]: population mode -- independent synthetic transients (config-2-like, 100 epochs x 6 filters
+    = 600 points, own truth drawn +-20 %), 512 walkers each, transients partitioned over the GPUs (no communication).
+    32 transients per GPU."""
+    import torch
+    dist, rank, world, local_rank = init_distributed(args)
+    from lightcurve_fitting_amd import models as M
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    n_tr, nw = 32 * world, 512
+    rng = np.random.default_rng(SEED + 5)
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
+    problems, x0, first_lc, first_truth = [], {}, None, None
+    for k in range(n_tr):
+        truth = TRUTH * rng.uniform(0.8, 1.2, 5)
+        epochs = np.sort(rng.uniform(0.5, 10., 100))
+        t, names = np.repeat(epochs, 6), list(np.tile(BANDS, 100))
+        model = M.ShockCooling(redshift=0.)
+        model.device = local_rank
+        noise = rng.standard_normal(600)
+        walkers = truth * rng.uniform(0.9, 1.1, (nw, 5))
+        if k * world // n_tr == rank:  # only this rank's share is built on the device
+            ytrue = model(t, names, *truth)
+            lc = {'MJD': t, 'filter': names, 'lum': ytrue * (1 + 0.05 * noise), 'dlum': 0.05 * ytrue}
+            problems.append((model, lc, priors))
+            if first_lc is None:
+                first_lc, first_truth = lc, truth
+        else:
+            problems.append((model, None, priors))
+        x0[k] = walkers
+    pop = PopulationSampler(problems, nw, seed=SEED, device=local_rank)
+    pop.run_mcmc(x0, args.warmup, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    pop.run_mcmc(None, args.steps, store=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0)
+    if rank == 0:
+        eng = pop[pop.indices[0]].engine
+        eng._variant = 2
+        quads = quads_per_evaluation(eng, first_truth)
+        pair_ms = pop.last_run_ms / (2 * args.steps)    # one k_step_multi + one k_points_multi per half-step
+        alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
+        roof = roofline_block('k_step_multi + k_points_multi (the two launches of a half-step of all 32 transients of this '
+                              'GPU; the likelihood launch dominates)', pair_ms, 32 * nw // 2, quads, VALU_PER_QUAD_F64,
+                              PEAK_FP64_TINSTR, alg_instr, ALG_BYTES, 'population')
+        out = {'metric': 'walker-steps/sec (population of independent ensembles)',
+               'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[4]: population mode, 32 transients per GPU x 512 walkers, 600 '
+                                      'points each (100 epochs x UBVgri)',
+                          'transients': n_tr, 'walkers_per_transient': nw, 'points': 600,
+                          'planck_samples_executed_per_eval': 4 * quads},
+               'roofline': roof, 'device_ms_per_step': pop.last_run_ms / args.steps}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import lcf_oracle as O
+            bands = [O.band(n) for n in first_lc['filter']]
+            mod = ('ShockCooling', O.ShockCoolingOracle(0., 1.5))
+            n, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 10.:
+                O.log_likelihood(mod, first_lc['MJD'], bands, first_lc['lum'], first_lc['dlum'],
+                                 x0[pop.indices[0]][n % nw], reference_shaped=True)
+                n += 1
+            dt = time.perf_counter() - t1
+            out['cpu_baseline'] = {'value': n / dt, 'unit': 'walker-steps/s', 'cores': 1, 'kind': 'port',
+                                   'sample': f'{n} per-walker log-likelihood evaluations of one transient (600 points, '
+                                             f'oracle in reference-shaped mode), {dt:.1f} s on 1 of {os.cpu_count()} cores'}
+            out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_sed(args):
+    """BASELINE configs[3]: per-epoch blackbody SED grid, 10 000 epochs x 6 filters (UBVgri) x 128 (T, R) candidates,
+    float32 arithmetic with the float64 kernel as the error reference.  Epochs are independent: N GPUs = N replicas of
+    an epoch shard (no communication); this line is the single-GPU figure."""
+    if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+        raise SystemExit('bench.py --workload sed: replicas only, run it with --gpus 1')
+    import torch  # noqa: F401  (one HIP runtime per process: see engine.load_library)
+    from lightcurve_fitting_amd import bolometric as B
+    from lightcurve_fitting_amd import models as M
+    from lightcurve_fitting_amd.filters import PackedTables
+    rng = np.random.default_rng(SEED + 4)
+    n_ep, n_c = 10000, 128
+    Tt, Rt = rng.uniform(5., 50., n_ep), 10 ** rng.uniform(-1., 2., n_ep)
+    ytrue = M.blackbody_to_filters(BANDS, Tt, Rt)                     # (6, n_ep) on the GPU
+    y = ytrue.T * (1. + 0.03 * rng.standard_normal((n_ep, 6)))
+    epochs = [(BANDS, y[e], 0.03 * ytrue[:, e]) for e in range(n_ep)]
+    cand = np.stack([rng.uniform(1., 100., (n_ep, n_c)), 10 ** rng.uniform(-2., 3., (n_ep, n_c))], axis=-1)
+    like = B.SpectrumLikelihood(epochs, z=0.)
+    out = {}
+    reps = max(3, args.steps // 20)
+    for prec in ('f32', 'f64'):
+        res = like(cand, precision=prec)                              # warm-up
+        ms = []
+        for _ in range(reps):
+            res = like(cand, precision=prec)
+            ms.append(like.engine.last_kernel_ms)
+        out[prec] = (res, float(np.median(ms)))
+    alg_samples = n_ep * n_c * (13 + 11 + 15 + 89 + 75 + 89)
+    # quads the kernel walks per candidate: the compressed ("cool") table of a filter where the candidate is hot enough
+    tabs = PackedTables(BANDS, z=0.)
+    per_cand = np.zeros(cand.shape[:2])
+    for f in range(6):
+        nfull, nc = tabs.off[f + 1] - tabs.off[f], tabs.coff[f + 1] - tabs.coff[f]
+        per_cand += (np.where((nc > 0) & (cand[..., 0] >= tabs.ctmin[f]), nc, nfull) + 3) // 4
+    quads = float(per_cand.mean())
+    err = np.abs(out['f32'][0] - out['f64'][0]) / np.abs(out['f64'][0])
+    roof = roofline_block('k_sed<1> (float32: one lane per candidate, band tables in LDS)', out['f32'][1], n_ep * n_c,
+                          quads, VALU_PER_QUAD_F32, PEAK_FP32_TINSTR, ALG_INSTR_PER_SAMPLE * 292 + 8 * 6, 8 * 3, 'k_sed')
+    line = {'metric': 'SED candidate evaluations/sec', 'value': n_ep * n_c / (out['f32'][1] * 1e-3),
+            'unit': 'candidates/s', 'n_gpus': 1, 'steps': reps, 'warmup': 1, 'ms_per_step': out['f32'][1],
+            'dtype': 'f32', 'data': 'synthetic', 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'config': {'workload': 'BASELINE configs[3]: 10000 epochs x 6 filters (UBVgri) x 128 (T,R) candidates',
+                       'planck_samples_per_launch': alg_samples, 'quads_executed_per_candidate': quads},
+            'kernel_ms_f32': out['f32'][1], 'kernel_ms_f64': out['f64'][1],
+            'planck_samples_per_s_f32': alg_samples / (out['f32'][1] * 1e-3),
+            'planck_samples_per_s_f64': alg_samples / (out['f64'][1] * 1e-3),
+            'f32_vs_f64_lnL_relative_error': {'max': float(err.max()), 'median': float(np.median(err))},
+            'roofline': roof}
+    if not args.no_cpu_baseline:
+        from oracle import lcf_oracle as O
+        bands = [O.band(n) for n in BANDS]
+        mod = ('Blackbody', O.ShockCoolingOracle(0., 1.5))
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.:
+            e, c = n % n_ep, (n // n_ep) % n_c
+            O.log_likelihood(mod, np.zeros(6), bands, y[e], 0.03 * ytrue[:, e], cand[e, c], reference_shaped=True)
+            n += 1
+        dt = time.perf_counter() - t0
+        line['cpu_baseline'] = {'value': n / dt, 'unit': 'candidates/s', 'cores': 1, 'kind': 'port',
+                                'sample': f'{n} candidate evaluations (6 filters each, oracle in reference-shaped mode), '
+                                          f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
+        line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: start the ranks here, BEFORE anything in this process initialises the GPU (torch is not even
+        # imported in the parent)
+        sys.exit(spawn_ranks(args.gpus))
+    if args.launch_check:
+        return launch_check(args)
+    {'mcmc': run_mcmc, 'companion': run_companion, 'population': run_population, 'sed': run_sed}[args.workload](args)
 
 
 if __name__ == '__main__':

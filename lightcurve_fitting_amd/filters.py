@@ -391,3 +391,15 @@ class PackedTables:
 
     def index(self, f):
         return self.filters.index(as_filter(f))
+
+    def samples_at(self, filt_idx, T, compressed=True):
+        """Samples the device band sum walks for points of filter ``filt_idx`` at temperature ``T`` [kK]: the shortest
+        table valid at that temperature (hot, else cool, else full), padded to quads as on the device."""
+        f = np.asarray(filt_idx)
+        T = np.broadcast_to(np.asarray(T, dtype=float), f.shape)
+        n = np.diff(self.off)[f]
+        if compressed:
+            nc, nh = np.diff(self.coff)[f], np.diff(self.hoff)[f]
+            n = np.where((nc > 0) & (T >= self.ctmin[f]), nc, n)
+            n = np.where((nh > 0) & (T >= self.htmin[f]), nh, n)
+        return np.where(T > 0., (n + 3) // 4 * 4, 0)

@@ -200,12 +200,14 @@ class Model:
         uniq, idx = _index_filters(filts)
         tabs = PackedTables(uniq, z=self.z, compress=not self.reddened, reddening=self.reddened)
         pri = None if priors is None else [p.descriptor() for p in priors]
-        return _eng.Engine(self.model_id, self.n_model_params, self._consts(), t, y, dy, idx, tabs.off, tabs.a, tabs.w,
-                           use_sigma=use_sigma, sigma_type=st, priors=pri,
-                           companion=self._companion_tables(uniq), device=self.device if device is None else device,
-                           ctab=None if self.reddened else (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
-                           htab=None if self.reddened else (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin),
-                           tab_ext=tabs.ext)
+        eng = _eng.Engine(self.model_id, self.n_model_params, self._consts(), t, y, dy, idx, tabs.off, tabs.a, tabs.w,
+                          use_sigma=use_sigma, sigma_type=st, priors=pri,
+                          companion=self._companion_tables(uniq), device=self.device if device is None else device,
+                          ctab=None if self.reddened else (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
+                          htab=None if self.reddened else (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin),
+                          tab_ext=tabs.ext)
+        eng.tables, eng.filt_idx = tabs, idx   # what was packed (measurement tools count the samples a fit executes)
+        return eng
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):
         """Engine bound to the photometry ``lc`` holds NOW (sigma mode and prior set as given).

@@ -1,36 +1,53 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the GPU box through gpurun).
-#   bash tools/collect_profiles.sh r01
+# Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the GPU box through gpurun, LAST in a round:
+# the PMC summaries carry the hash of the kernel sources they were collected from, and bench.py uses them only while
+# that hash matches the tree).
+#   bash tools/collect_profiles.sh r02 [commit]
 # kernel-trace/stats and every --pmc pass are separate runs, as the profiling guide prescribes.
-set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT
+mkdir -p $OUT $R/profiles
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 1000 --warmup 20 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
-for V in 2 1; do
-i=0
-for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
-         "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/v${V}_pmc$i -- python3 $R/tools/prof_kernel.py 3 $V > $OUT/v${V}_pmc$i.log 2>&1
-done
-python3 - "$OUT" "$V" <<'PY'
+declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
+declare -A PSTEPS=( [mcmc]=5 [companion]=2 [population]=3 [sed]=1 )
+declare -A KERNEL=( [mcmc]=k_solo [companion]=k_solo [population]=k_points_multi [sed]=k_sed )
+declare -A PTAG=( [mcmc]=k_solo_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
+for W in mcmc companion population sed; do
+  echo "== $W: kernel trace"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 $R/bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/trace_$W.log
+  cp $OUT/trace_$W/*/*_kernel_stats.csv $R/profiles/${TAG}_kernel_stats_$W.csv 2>/dev/null
+  i=0
+  for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    echo "== $W: pmc pass $i"
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${W}_$i -- python3 $R/tools/prof_kernel.py $W ${PSTEPS[$W]} > $OUT/pmc_${W}_$i.log 2>&1
+  done
+  python3 - "$OUT" "$W" "${KERNEL[$W]}" "$R/profiles/${TAG}_pmc_${PTAG[$W]}.json" "$COMMIT" "$R" <<'PY'
 import csv, glob, collections, json, sys
-out, variant = sys.argv[1], sys.argv[2]
-res = {}
-for p in sorted(glob.glob(out + f'/v{variant}_pmc*/*/*_counter_collection.csv')):
+out, w, kern, dst, commit, root = sys.argv[1:7]
+sys.path.insert(0, root)
+import bench
+res, name = {}, None
+for p in sorted(glob.glob(out + f'/pmc_{w}_*/*/*_counter_collection.csv')):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if 'k_fused' in r['Kernel_Name']:
+        if kern in r['Kernel_Name']:
+            name = r['Kernel_Name'].split('(')[0]
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         res[k] = {'mean_per_launch': sum(v) / len(v), 'launches': len(v)}
-json.dump(res, open(out + f'/pmc_k_fused_v{variant}.json', 'w'), indent=1)
-print(variant, json.dumps(res))
+json.dump({'workload': w, 'kernel': name, 'collected_at_commit': commit, 'kernel_source_sha256': bench.kernel_source_sha(),
+           'counters': res}, open(dst, 'w'), indent=1)
+print(w, name, {k: round(v['mean_per_launch'], 1) for k, v in res.items()})
 PY
 done
-for f in $OUT/pmc_k_fused_v*.json; do cp $f $R/profiles/${TAG}_$(basename $f); done
-python3 $R/bench.py --steps 1000 --warmup 20 --full-tables-reference > $OUT/bench_unprofiled.json 2> /dev/null  # -> profiles/<tag>_bench_line_full_tables.json
-cp $OUT/trace/*/*_kernel_stats.csv $OUT/kernel_stats.csv
+echo "== unprofiled bench lines"
+cd $R
+for W in mcmc companion population sed; do
+  python3 bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 > profiles/${TAG}_bench_$W.json 2> /dev/null
+done
+python3 bench.py --steps 1000 --warmup 5 --variant 1 --no-cpu-baseline > profiles/${TAG}_bench_mcmc_full_tables.json 2> /dev/null
+ls -la profiles/ | tail -20
