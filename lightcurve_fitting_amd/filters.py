@@ -90,19 +90,61 @@ COMPRESSION_TOL = 2e-14
 #: lowest temperatures [kK] down to which the two compressed levels must hold (see PackedTables)
 COOL_TMIN = 1.0
 HOT_TMIN = 8.0
-_T_GRID = np.geomspace(0.2, 2e4, 101)
+_T_GRID = np.geomspace(0.2, 2e4, 101)      # coarse grid: finds the order and a first t_min
+_DENSE_N, _DENSE_TMAX = 2048, 1e5          # dense proof grid: 2048 temperatures from t_min to 1e5 kK
+
+
+def band_sum_exact(a, w, temps):
+    """``sum_k W_k / (e^{a_k / T} - 1)`` in extended precision for an array of temperatures: the yardstick the
+    compressed tables are proved against (and nothing the engine computes with)."""
+    ld = np.longdouble
+    x = np.multiply.outer(1. / np.asarray(temps, dtype=ld), np.asarray(a, dtype=ld))
+    with np.errstate(over='ignore'):
+        return (np.asarray(w, dtype=ld) / np.expm1(x)).sum(axis=1)
+
+
+def compression_error(a, w, ag, wg, t_min, n=_DENSE_N, t_max=_DENSE_TMAX):
+    """Largest relative difference between the compressed and the full band sum on ``n`` log-spaced temperatures from
+    ``t_min`` to ``t_max`` (extended precision on both sides), and the temperature at which it occurs.  Beyond
+    ``t_max`` the summand tends to ``T / a_k``: the error there is the one at ``t_max`` (a_k / T < 2e-3)."""
+    temps = np.geomspace(max(t_min, _T_GRID[0]), t_max, n)
+    full, comp = band_sum_exact(a, w, temps), band_sum_exact(ag, wg, temps)
+    err = np.abs(comp - full) / np.abs(full)
+    k = int(np.argmax(err))
+    return float(err[k]), float(temps[k]), temps, err
+
+
+_compressed = {}   # proved levels by content: engines of one process share filters, redshift and cut-off
 
 
 def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32), max_tmin=2.0, min_ratio=2.):
+    """:func:`prove_compressed_table`, remembered per table content and arguments."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    key = (a.tobytes(), w.tobytes(), float(tol), tuple(orders), float(max_tmin), float(min_ratio))
+    if key not in _compressed:
+        if len(_compressed) > 512:
+            _compressed.clear()
+        _compressed[key] = prove_compressed_table(a, w, tol, orders, max_tmin, min_ratio)
+    return _compressed[key]
+
+
+def prove_compressed_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32), max_tmin=2.0, min_ratio=2.):
     """Shorter table ``(a', W')`` with ``sum W'/(e^{a'/T} - 1) == sum W/(e^{a/T} - 1)`` to ``tol`` for every
     temperature ``T >= t_min``: the Gauss rule of the table's own discrete measure (1/(e^{a/T} - 1) is analytic in a,
     so a rule exact to polynomial degree 2m-1 converges geometrically in m; it degrades only when the band spans many
-    e-folds, i.e. at low T).  Returns ``(a', W', t_min)`` or ``None`` when no order up to K/2 reaches ``tol`` at 2 kK.
-    Verified here against the full sum on a temperature grid; the engine uses the full table below ``t_min``."""
+    e-folds, i.e. at low T).
+
+    A rule is first located on a coarse temperature grid and then PROVED on a dense one -- 2048 temperatures from its
+    ``t_min`` to 1e5 kK, extended precision, for exactly the samples given (redshift and cut-off included): a level
+    whose dense error exceeds ``tol`` has its ``t_min`` raised above the failing temperatures and is proved again, or is
+    dropped (the engine then walks the next longer table: fail closed).  Returns ``(a', W', t_min, bound)`` with
+    ``bound`` the largest relative error found, or ``None``."""
     a = np.asarray(a, dtype=np.float64)
     w = np.asarray(w, dtype=np.float64)
     with np.errstate(over='ignore'):
         full = np.array([np.sum(w / np.expm1(a / t)) for t in _T_GRID])
+    step = _T_GRID[1] / _T_GRID[0]
     for m in orders:
         if min_ratio * m > len(a):
             break
@@ -114,10 +156,18 @@ def compress_planck_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32), ma
         ok = np.abs(comp - full) <= tol * np.abs(full)
         bad = np.nonzero(~ok)[0]
         first_good = 0 if len(bad) == 0 else bad[-1] + 1
-        if first_good < len(_T_GRID) and _T_GRID[first_good] <= max_tmin:
-            # one grid step of margin above the last failing temperature
-            t_min = _T_GRID[min(first_good + 1, len(_T_GRID) - 1)] if len(bad) else 0.
-            return np.ascontiguousarray(ag[::-1]), np.ascontiguousarray(wg[::-1]), float(t_min)
+        if not (first_good < len(_T_GRID) and _T_GRID[first_good] <= max_tmin):
+            continue
+        # one coarse grid step of margin above the last failing temperature (never below the grid's lower end)
+        t_min = float(_T_GRID[min(first_good + 1, len(_T_GRID) - 1)] if len(bad) else _T_GRID[0])
+        ag, wg = np.ascontiguousarray(ag[::-1]), np.ascontiguousarray(wg[::-1])
+        for _ in range(3):  # the proof; a failure between coarse points raises t_min and is proved again
+            bound, _, temps, err = compression_error(a, w, ag, wg, t_min)
+            if bound <= tol:
+                return ag, wg, t_min, bound
+            t_min = float(temps[np.nonzero(err > tol)[0][-1]] * step)
+            if t_min > max_tmin:
+                break
     return None
 
 
@@ -362,7 +412,7 @@ class PackedTables:
         def quads(n):
             return (n + 3) // 4
 
-        levels = {'c': ([], [], [0], []), 'h': ([], [], [0], [])}
+        levels = {'c': ([], [], [0], [], []), 'h': ([], [], [0], [], [])}
         for i in range(len(self.filters)):
             a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
             cool = compress_planck_table(a, w, orders=(8, 12, 16, 20, 24, 28, 32), max_tmin=COOL_TMIN,
@@ -374,20 +424,25 @@ class PackedTables:
             if hot is not None and (quads(len(hot[0])) >= quads(longer) or (cool is not None and hot[2] <= cool[2])):
                 hot = None
             for key, comp in (('c', cool), ('h', hot)):
-                aa, ww, oo, tt = levels[key]
+                aa, ww, oo, tt, bb = levels[key]
                 if comp is None:
                     tt.append(np.inf)
+                    bb.append(np.nan)
                 else:
                     aa.append(comp[0])
                     ww.append(comp[1])
                     tt.append(comp[2])
+                    bb.append(comp[3])
                 oo.append(oo[-1] + (0 if comp is None else len(comp[0])))
-        for key, names in (('c', ('ca', 'cw', 'coff', 'ctmin')), ('h', ('ha', 'hw', 'hoff', 'htmin'))):
-            aa, ww, oo, tt = levels[key]
+        #: per filter: largest relative error of each compressed level against the full sum, proved on the dense
+        #: temperature grid from the level's t_min to 1e5 kK (NaN: the level does not exist)
+        for key, names in (('c', ('ca', 'cw', 'coff', 'ctmin', 'cbound')), ('h', ('ha', 'hw', 'hoff', 'htmin', 'hbound'))):
+            aa, ww, oo, tt, bb = levels[key]
             setattr(self, names[0], np.concatenate(aa) if aa else np.zeros(0))
             setattr(self, names[1], np.concatenate(ww) if ww else np.zeros(0))
             setattr(self, names[2], np.asarray(oo, dtype=np.int32))
             setattr(self, names[3], np.asarray(tt, dtype=np.float64))
+            setattr(self, names[4], np.asarray(bb, dtype=np.float64))
 
     def index(self, f):
         return self.filters.index(as_filter(f))

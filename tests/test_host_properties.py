@@ -92,3 +92,37 @@ def test_packed_tables_every_level_gives_the_same_band_sum(names, z, T):
                 with np.errstate(over='ignore'):
                     comp = np.sum(cw / np.expm1(ca / T))
                 assert abs(comp - full) <= 4e-14 * abs(full)
+
+
+_ALL_TABLES = [f.name for f in F.all_filters if f.filename]
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.lists(st.floats(0., 1.), min_size=24, max_size=24), st.sampled_from([np.inf, 1500.]))
+def test_every_compressed_level_of_every_table_is_proved(us, cutoff):
+    """All bandpass tables x z in {0, 0.5, 2} (x a cut-off frequency): each compressed level carries the bound of its
+    pack-time proof (2048 temperatures from its t_min to 1e5 kK, extended precision, <= COMPRESSION_TOL), and at
+    temperatures drawn BETWEEN the proof temperatures -- log-uniform over the same range, the level's own t_min and
+    1e5 kK included -- it stays within 1.25 x the tolerance of the full sum (neighbouring proof temperatures are 0.64 %
+    apart; the error is a smooth function of T).  A level that cannot be proved does not exist (t_min = inf)."""
+    assert len(_ALL_TABLES) >= 59
+    n_levels = 0
+    for z in (0., 0.5, 2.):
+        tabs = F.PackedTables(_ALL_TABLES, z=z, cutoff_freq=cutoff)   # (proofs are cached per table content)
+        for i in range(len(_ALL_TABLES)):
+            a, w = tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]]
+            for oo, aa, ww, tt, bb in ((tabs.coff, tabs.ca, tabs.cw, tabs.ctmin, tabs.cbound),
+                                       (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin, tabs.hbound)):
+                n = oo[i + 1] - oo[i]
+                if n == 0:
+                    assert np.isinf(tt[i]) and np.isnan(bb[i])
+                    continue
+                n_levels += 1
+                assert 0.2 <= tt[i] <= 1.13 * F.HOT_TMIN and 0. <= bb[i] <= F.COMPRESSION_TOL  # (one grid step of margin)
+                u = np.array(us[(i + n_levels) % 8::8][:3] + [0., 1.])
+                temps = tt[i] * (1e5 / tt[i]) ** u
+                full = F.band_sum_exact(a, w, temps)
+                comp = F.band_sum_exact(aa[oo[i]:oo[i + 1]], ww[oo[i]:oo[i + 1]], temps)
+                err = np.abs(comp - full) / np.abs(full)
+                assert np.all(err <= 1.25 * F.COMPRESSION_TOL), (_ALL_TABLES[i], z, temps[np.argmax(err)], err.max())
+    assert n_levels > 150
