@@ -84,6 +84,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variant', type=int, default=2,
                     help='band sum: 2 = Gauss-compressed tables (default), 1 = the full tables, 0 = libm')
+    ap.add_argument('--collective', choices=['allgather', 'peers'], default='allgather',
+                    help='N > 1: how the ranks exchange the rows of a half-step: one RCCL all-gather (default), or direct '
+                         "stores into every rank's mailbox over IPC-mapped memory (no collective; experimental)")
     ap.add_argument('--launch-check', action='store_true',
                     help='only start the ranks, let them find each other (gloo) and print what they saw')
     return ap.parse_args(argv)
@@ -186,9 +189,14 @@ def collective_info(sampler, dist, world):
     """Which driver a multi-rank run used, the communicator's own rank count, one all-gather's time."""
     if dist is None:
         return None
-    comm = sampler._native_comm()
     n_half = (sampler.nwalkers + 1) // 2
     rows = sampler._native.rows_ptr()[1]
+    if sampler.collective == 'peers' and sampler._peers:
+        return {'driver': "peer mailboxes: every rank stores its shard's rows straight into all ranks' mailboxes "
+                          '(IPC-mapped device memory) and polls its own; no collective, no launch between half-steps',
+                'rccl_comm_ranks': None, 'group_ranks': dist.get_world_size(), 'allgather_us': None,
+                'payload_bytes_per_rank': 16 * rows * n_half // world}
+    comm = sampler._native_comm()
     if comm is not None:
         n, r = comm.count()
         return {'driver': 'native: lcf_sampler_run_sharded, ncclAllGather enqueued per half-step',
@@ -396,7 +404,7 @@ def run_mcmc(args):
     engine._variant = args.variant
     scaling = args.scaling or 'weak'
     n_walkers = WALKERS_PER_GPU * (world if scaling == 'weak' else 1)
-    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED)
+    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=args.collective)
     x0 = initial_walkers(n_walkers)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = n_walkers * args.steps / elapsed
@@ -488,7 +496,7 @@ def run_companion(args):
     nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
     engine = model.engine_for(lc, priors=priors)
     engine._variant = 2
-    sampler = EnsembleSampler(nw, 8, engine, seed=SEED)
+    sampler = EnsembleSampler(nw, 8, engine, seed=SEED, collective=args.collective)
     x0 = companion_walkers(nw)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = nw * args.steps / elapsed

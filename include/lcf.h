@@ -252,6 +252,26 @@ lcf_status lcf_comm_time_allgather(lcf_comm* c, lcf_sampler* s, int32_t reps, do
 lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_step, int64_t n_steps,
                                    int32_t split_mode, const int32_t* perm, int32_t store_chain);
 
+/* ---- sharded run WITHOUT a collective: peer mailboxes (behind a switch until measured on a multi-GPU node) ---------- */
+/* Every rank owns a mailbox in uncached device memory; a rank that has evaluated a proposal stores the numbers of its
+ * row -- each as two 8-byte {data, generation} granules -- straight into every rank's mailbox (peers' memory mapped
+ * through HIP IPC: xGMI writes on a node) and the accept tests of the next launch poll their own copy.  No kernel and
+ * no host call sits between two half-steps.  Set-up: every rank exports its mailbox, the handles travel by any means
+ * (the Python driver uses torch.distributed), every rank connects with the full list.  `local_ptrs` (instead of
+ * handles): ranks emulated inside one process pass each other's device pointers.  At most 8 ranks. */
+typedef struct { char internal[64]; } lcf_ipc_handle;
+lcf_status lcf_sampler_mailbox_export(lcf_sampler* s, lcf_ipc_handle* out, void** local_ptr);
+lcf_status lcf_sampler_mailbox_connect(lcf_sampler* s, int32_t n_ranks, int32_t rank, const lcf_ipc_handle* handles,
+                                       void* const* local_ptrs);
+/* The run of lcf_sampler_run_sharded over the mailboxes.  Every rank calls it with the same arguments, and only after
+ * ALL ranks have returned from their previous run (barrier of the caller).  A rank whose peers' rows do not arrive
+ * within 0.5 s returns LCF_ERR_STATE instead of waiting for ever. */
+lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 const int32_t* perm, int32_t store_chain);
+/* Enqueue only (lcf_sampler_wait completes it): lets one host thread drive several emulated ranks. */
+lcf_status lcf_sampler_run_peers_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                       const int32_t* perm, int32_t store_chain);
+
 /* ---- per-epoch blackbody SED likelihood (bolometric.py:154-164: spectrum_mcmc's inner log_posterior) --------- */
 /* For every epoch e, observations ep_off[e] .. ep_off[e+1]-1 (filter index, luminosity density y, uncertainty dy);
  * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged

@@ -17,6 +17,7 @@ constexpr int kNCoef = 8;        // derived per-walker coefficients
 constexpr int kMaxDim = 16;      // max parameters per walker
 constexpr int kLdsFiltMax = 64;   // filters whose descriptors are staged with the tables
 constexpr int kLdsTabMax = 3700; // (a,W) pairs staged per workgroup (< 64 KiB with the exp table)
+constexpr int kMaxPeers = 8;     // ranks of a peer-mailbox run (the GPUs of one node)
 
 constexpr double kKB = 0.08617333262145178;   // eV / kK                 models.py:10
 constexpr double kC3 = 5.38477047522316e-19;  //                          models.py:11

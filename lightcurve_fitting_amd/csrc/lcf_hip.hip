@@ -251,12 +251,15 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
 }
 
 // Workgroup reduction of the chi^2 shares in a fixed order; thread 0 stores the part's partial sum.
-__device__ inline void store_part_sum(double term, double* __restrict__ red, double* __restrict__ dst) {
+__device__ inline double store_part_sum(double term, double* __restrict__ red, double* __restrict__ dst) {
     const int tid = threadIdx.x;
     const double ws = wave_sum(term);
     if ((tid & 63) == 0) red[tid >> 6] = ws;
     __syncthreads();
-    if (tid == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid != 0) return 0.;
+    const double sum = (red[0] + red[1]) + (red[2] + red[3]);
+    *dst = sum;
+    return sum;  // (thread 0)
 }
 
 // MODE 0: chi^2 partial sums -> part[w][n_parts];  MODE 1: y_fit -> out0[w][orig];  MODE 2: T, R_bb -> out0, out1
@@ -367,7 +370,7 @@ struct DevSampler {
     int n_walkers, n_half, n_dim, store_chain;
     uint32_t key0, key1;
     int inline_finalize;  // 1: accept tests sum the chi^2 partials themselves; 0: they read the gathered newlp
-    int pad;
+    int n_peers;          // > 0: the rows travel through peer mailboxes (below) instead of part2 + a collective
     double a;
     double* X;          // [n_walkers][n_dim]  committed positions
     double* LP;         // [n_walkers]         committed log-posteriors
@@ -379,7 +382,48 @@ struct DevSampler {
     double* chain_lp;   // [n_steps][n_walkers]
     long long* nacc;    // [n_walkers]
     int* err;
+    // Peer mailboxes (multi-GPU without a collective): every rank owns a mailbox [4 generations][n_half][row] of
+    // 16-byte entries; a rank that has evaluated a proposal writes the entry of each of the row's numbers straight into
+    // EVERY rank's mailbox (peer memory mapped through IPC; over xGMI on a node), and whoever needs the row polls its
+    // own copy.  mbox = this rank's, peer_mbox[r] = rank r's as mapped here (own included).
+    unsigned long long* mbox;
+    unsigned long long* peer_mbox[kMaxPeers];
 };
+
+// One float64 as two 8-byte granules {32 data bits, 32-bit generation tag}: an 8-byte store is the largest that
+// arrives whole, so a reader that sees the tag of the generation it waits for in both granules has the value -- no
+// flag, no fence, no ordering between stores needed (the "LL" protocol of the collective libraries).  Mailbox
+// memory is uncached (fine-grained); stores and polls are system-scope so that they bypass the XCD's L2.
+__device__ inline void mbox_post(const DevSampler& sm, long long g, int slot, int col, int stride, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)(uint32_t)g << 32;
+    const size_t at = 2 * ((((size_t)(g & 3) * sm.n_half) + slot) * stride + col);
+#pragma unroll
+    for (int r = 0; r < kMaxPeers; ++r)
+        if (r < sm.n_peers) {
+            unsigned long long* p = sm.peer_mbox[r] + at;
+            __hip_atomic_store(p, (b & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p + 1, (b >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+}
+
+// The value of generation g, once it has arrived; every lane's wait is bounded (0.5 s of the 100 MHz wall clock): a
+// peer that never delivers ends the run with an error instead of hanging the device.
+__device__ inline double mbox_take(const DevSampler& sm, long long g, int slot, int col, int stride) {
+    const unsigned long long tag = (unsigned long long)(uint32_t)g;
+    const unsigned long long* p = sm.mbox + 2 * ((((size_t)(g & 3) * sm.n_half) + slot) * stride + col);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((a >> 32) == tag && (b >> 32) == tag)
+            return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        if (wall_clock64() - t0 > 50000000ull) {
+            atomicOr(sm.err, 2);
+            return qnan();
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 
 // Random red/blue colouring of each step (emcee's randomize_split): one workgroup per step ranks the walkers by a
 // 50-bit Philox key (ties impossible: the walker id fills the low 14 bits) with a bitonic sort in LDS.
@@ -524,7 +568,16 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
 #pragma unroll
             for (int d = 0; d < kD; ++d)
                 if (d < nd) qrow[d] = qs[d];
-            if (sm.inline_finalize) {
+            if (sm.n_peers > 0) {
+                // the slot's row from this rank's mailbox, as its owner posted it: the log-prior first (always posted;
+                // the partial sums only where the prior allows the proposal)
+                const int stride = part_stride(pb);
+                const double lpri = mbox_take(sm, g - 1, rslot, pb.n_parts, stride);
+                double sum = pb.use_sigma ? 0. : pb.log_norm_const;
+                if (lpri != -INFINITY)
+                    for (int k = 0; k < pb.n_parts; ++k) sum += mbox_take(sm, g - 1, rslot, k, stride);
+                nlp = lpri == -INFINITY ? -INFINITY : lpri - 0.5 * sum;
+            } else if (sm.inline_finalize) {
                 // the slot's row: partial chi^2 sums, then the log-prior (of this rank's evaluation, or gathered)
                 const double* prow = sm.part2[pp] + (size_t)rslot * part_stride(pb);
                 double sum = pb.use_sigma ? 0. : pb.log_norm_const;
@@ -543,7 +596,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
         }
     }
     if (lane == 0 && rslot >= 0) {  // commit of the previous half-step's slot i
-        if (nlp != nlp) atomicExch(sm.err, 1);
+        if (nlp != nlp) atomicOr(sm.err, 1);
         if (ok) {
 #pragma unroll
             for (int d = 0; d < kD; ++d)
@@ -620,6 +673,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
                     if (d < nd) sm.Q[cp][(size_t)i * nd + d] = q[d];
                 sm.rec[cp][i] = SlotRec{dr.zl, dr.lnu, lp_i, lpr};
                 sm.part2[cp][(size_t)i * part_stride(pb) + pb.n_parts] = lpr;  // last column of the slot's row
+                if (sm.n_peers > 0) mbox_post(sm, g, i, pb.n_parts, part_stride(pb), lpr);
                 if (coef)
                     for (int k = 0; k < kNCoef; ++k) coef[(size_t)i * kNCoef + k] = c[k];
                 if (lprior) lprior[i] = lpr;
@@ -763,7 +817,8 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     if (THERM || reddened) __syncthreads();
     const double term = points_loop<VARIANT, 0, true, THERM>(pb, part, 0, sq, cs, lth, e0, ltab, fdesc, ExpTab{exptab},
                                                              nullptr, nullptr);
-    store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
+    const double psum = store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
+    if (sm.n_peers > 0 && tid == 0) mbox_post(sm, g, i, part, part_stride(pb), psum);  // straight into every rank's mailbox
 }
 
 // Diagnostic build only (-DLCF_STAMPS, tools/debug/make_stamp_build.py; never shipped): s_memtime stamps of the first 64
@@ -924,7 +979,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     }
     const double lp_i = sx[kMaxDim];
     const bool ok = (dr.zl + nlp - lp_i) > dr.lnu;   // emcee: (ndim - 1) ln z + lp_new - lp_old > ln u
-    if (nlp != nlp) atomicExch(sm.err, 1);
+    if (nlp != nlp) atomicOr(sm.err, 1);
     if (ok) {
 #pragma unroll
         for (int d = 0; d < kD; ++d)
@@ -1616,6 +1671,9 @@ struct lcf_sampler {
     bool pending = false;     // the last proposed half-step is not committed yet
     bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
     int half_step_kernel = LCF_HALF_STEP_AUTO;
+    unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
+    std::vector<void*> opened;               // peers' mailboxes mapped through IPC
+    int peer_ranks = 0, peer_rank = 0;
     // Snapshot of (error flag, positions, log-posteriors, acceptance counts) in pinned host memory, copied behind the
     // last launch of a run: the calls that read them back after the run wait for nothing more.
     unsigned char* snap = nullptr;
@@ -1633,6 +1691,8 @@ struct lcf_sampler {
         if (ds.chain) hipFree(ds.chain);
         if (ds.chain_lp) hipFree(ds.chain_lp);
         free_blocks();
+        for (void* p : opened) hipIpcCloseMemHandle(p);
+        if (mailbox) hipFree(mailbox);
         if (snap) hipHostFree(snap);
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
@@ -2251,6 +2311,7 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (lcf_status st = settle(s)) return st;
     int err = 0;
     std::memcpy(&err, s->snap, sizeof(int));
+    if (err & 2) return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;
 }
@@ -2396,6 +2457,94 @@ lcf_status lcf_sampler_run_sharded(lcf_sampler* s, lcf_comm* c, int64_t first_st
     if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
     if (lcf_status r = enqueue_snapshot(s)) return r;
+    return lcf_sampler_wait(s);
+}
+
+// ---- peer mailboxes: a sharded run without a collective ---------------------------------------------------------------
+namespace {
+size_t mailbox_bytes(const lcf_sampler* s) {
+    return (size_t)4 * s->ds.n_half * (s->e->dp.n_parts + 1) * 2 * sizeof(unsigned long long);
+}
+lcf_status mailbox_alloc(lcf_sampler* s) {
+    if (s->mailbox) return LCF_OK;
+    LCF_HIP(hipSetDevice(s->e->device));
+    // uncached (fine-grained) device memory: peers' stores over the fabric and this rank's polls meet in memory
+    LCF_HIP(hipExtMallocWithFlags((void**)&s->mailbox, mailbox_bytes(s), hipDeviceMallocUncached));
+    LCF_HIP(hipMemset(s->mailbox, 0, mailbox_bytes(s)));  // tag 0: no generation (half-steps are numbered from 2)
+    return LCF_OK;
+}
+}  // namespace
+
+lcf_status lcf_sampler_mailbox_export(lcf_sampler* s, lcf_ipc_handle* out, void** local_ptr) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (lcf_status st = mailbox_alloc(s)) return st;
+    if (out) {
+        static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(lcf_ipc_handle), "IPC handle size");
+        hipIpcMemHandle_t h;
+        LCF_HIP(hipIpcGetMemHandle(&h, s->mailbox));
+        std::memset(out, 0, sizeof(*out));
+        std::memcpy(out, &h, sizeof(h));
+    }
+    if (local_ptr) *local_ptr = s->mailbox;
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_mailbox_connect(lcf_sampler* s, int32_t n_ranks, int32_t rank, const lcf_ipc_handle* handles,
+                                       void* const* local_ptrs) {
+    if (!s || n_ranks < 1 || n_ranks > kMaxPeers || rank < 0 || rank >= n_ranks || (!handles && !local_ptrs))
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument (at most 8 ranks)");
+    if (s->ds.n_half % n_ranks)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "the slots of a half-step must divide evenly over the ranks");
+    if (!fused_eligible(s)) return fail(LCF_ERR_UNSUPPORTED, "peer-mailbox runs need the one-launch half-step (k_fused)");
+    if (lcf_status st = mailbox_alloc(s)) return st;
+    LCF_HIP(hipSetDevice(s->e->device));
+    for (int r = 0; r < n_ranks; ++r) {
+        void* p = nullptr;
+        if (r == rank) {
+            p = s->mailbox;
+        } else if (local_ptrs) {  // ranks emulated inside one process: plain device pointers
+            p = local_ptrs[r];
+        } else {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, &handles[r], sizeof(h));
+            LCF_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            s->opened.push_back(p);
+        }
+        if (!p) return fail(LCF_ERR_INVALID_ARGUMENT, "null peer mailbox");
+        s->ds.peer_mbox[r] = static_cast<unsigned long long*>(p);
+    }
+    s->ds.mbox = s->mailbox;
+    s->peer_ranks = n_ranks;
+    s->peer_rank = rank;
+    return LCF_OK;
+}
+
+// The run of lcf_sampler_run_sharded without its collective: every launch posts the rows of this rank's shard into
+// all ranks' mailboxes and polls its own for the rows it needs.  Collective in effect: every rank must call it with the
+// same arguments, after ALL ranks have returned from the previous run (the caller's barrier).
+lcf_status lcf_sampler_run_peers_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                       const int32_t* perm, int32_t store_chain) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->peer_ranks < 1) return fail(LCF_ERR_STATE, "lcf_sampler_mailbox_connect must be called first");
+    if (!fused_eligible(s)) return fail(LCF_ERR_UNSUPPORTED, "peer-mailbox runs need the one-launch half-step (k_fused)");
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, true)) return st;
+    hipStream_t st = s->e->stream;
+    const int width = s->ds.n_half / s->peer_ranks, lo = s->peer_rank * width, hi = lo + width;
+    s->ds.inline_finalize = 1;
+    s->ds.n_peers = s->peer_ranks;
+    LCF_HIP(hipEventRecord(s->ev0, st));
+    lcf_status rc = LCF_OK;
+    for (int64_t k = 0; k < 2 * n_steps && rc == LCF_OK; ++k) rc = launch_fused(s, lo, hi, st);
+    if (rc == LCF_OK) rc = flush_pending(s, st);
+    s->ds.n_peers = 0;  // (kernel arguments are captured at launch: later runs of other kinds are unaffected)
+    if (rc != LCF_OK) return rc;
+    LCF_HIP(hipEventRecord(s->ev1, st));
+    return enqueue_snapshot(s);
+}
+
+lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 const int32_t* perm, int32_t store_chain) {
+    if (lcf_status st = lcf_sampler_run_peers_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     return lcf_sampler_wait(s);
 }
 

@@ -258,7 +258,7 @@ class EnsembleSampler:
     """
 
     def __init__(self, nwalkers, ndim, engine, seed=0, a=2.0, randomize_split=True, group=None,
-                 force_sharded=False, native_collectives=True):
+                 force_sharded=False, native_collectives=True, collective=None):
         from .engine import NativeSampler
         if nwalkers < 2 * ndim:  # emcee's check; odd ensembles are fine (the red-blue split is then ceil / floor)
             raise ValueError('It is unadvisable to use a red-blue move with fewer walkers than twice the number of '
@@ -273,6 +273,14 @@ class EnsembleSampler:
         self._group = group
         self._force_sharded = force_sharded  # run the phase-by-phase collective path even with a single rank
         self.native_collectives = native_collectives
+        #: how the ranks of a multi-GPU run exchange the rows of a half-step: 'allgather' (default: one RCCL all-gather
+        #: per half-step) or 'peers' (direct stores into every rank's mailbox over IPC-mapped memory, no collective;
+        #: behind this switch / LCF_COLLECTIVE=peers until it has been measured on a multi-GPU node)
+        import os
+        self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'allgather')
+        if self.collective not in ('allgather', 'peers'):
+            raise ValueError("collective must be 'allgather' or 'peers'")
+        self._peers = None  # True once the mailboxes are connected, False if unavailable
         self._comm = None  # NativeComm once created, False if unavailable
         self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
         self._chain = np.empty((0, nwalkers, ndim))
@@ -313,6 +321,38 @@ class EnsembleSampler:
                     comm = None
             self._comm = comm if comm is not None else False
         return self._comm or None
+
+    def _peer_mailboxes(self):
+        """Connect the ranks' mailboxes (once): every rank exports an IPC handle, the handles travel over
+        torch.distributed, every rank maps them all.  All ranks take the same decision (all-reduce of the outcome)."""
+        if self._peers is None:
+            import torch
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(self._group), dist.get_rank(self._group)
+            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+
+            def agreed(ok):
+                flag = torch.tensor([1 if ok else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+                return int(flag.item()) == 1
+
+            handle = None
+            try:
+                if world <= 8 and ((self.nwalkers + 1) // 2) % world == 0 and self._native.one_launch:
+                    handle, _ = self._native.mailbox_export()
+            except Exception:  # noqa: BLE001 - then every rank falls back to the all-gather
+                handle = None
+            ok = agreed(handle is not None)
+            if ok:
+                handles = [None] * world
+                dist.all_gather_object(handles, handle, group=self._group)
+                try:
+                    self._native.mailbox_connect(world, rank, handles=handles)
+                except Exception:  # noqa: BLE001
+                    ok = False
+                ok = agreed(ok)
+            self._peers = ok
+        return self._peers
 
     def _distributed(self):
         try:
@@ -359,7 +399,11 @@ class EnsembleSampler:
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         self._in_flight = False
         try:
-            if self._distributed() and self._native_comm() is not None:
+            if self._distributed() and self.collective == 'peers' and self._peer_mailboxes():
+                import torch.distributed as dist
+                dist.barrier(group=self._group)  # every rank has returned from its previous run (see lcf_sampler_run_peers)
+                self._native.run_peers(self._steps_done, nsteps, split, store)
+            elif self._distributed() and self._native_comm() is not None:
                 self._native.run_sharded(self._comm, self._steps_done, nsteps, split, store)
             elif self._distributed():
                 ShardedStretchDriver(NativeBackend(self._native, rows=True), self._group,

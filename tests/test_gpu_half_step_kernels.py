@@ -150,3 +150,54 @@ def test_engine_follows_the_light_curve_content():
     s.run_mcmc(P[:1] * (1 + 0.01 * np.random.default_rng(1).standard_normal((12, 5))), 3)
     assert np.all(np.isfinite(s.get_log_prob()))
     assert relerr(eng.log_likelihood(P), before) == 0.
+
+
+@pytest.mark.parametrize('ranks', [2, 3])
+def test_peer_mailboxes_emulated_ranks(ranks):
+    """The collective-free sharded run: `ranks` samplers on engines (= streams) of their own play the ranks of one
+    ensemble; each stores the rows of its shard straight into every mailbox and polls its own.  Their launches run
+    concurrently on the device; every rank must reproduce the single-GPU chain bit for bit.  (No more than three: a
+    process gets four hardware queues, and streams that share one run in order -- a rank would wait for a rank queued
+    behind it until the 0.5 s bound.  Real ranks are processes: tools/peer_ranks_check.py.)"""
+    pb, eng = _multiband()
+    nwalkers, nsteps = 48, 9
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(4).standard_normal((nwalkers, 5)))
+    _, want_chain, want_lp, want_acc, _ = _run(eng, nwalkers, 321, x0, nsteps, 'auto')
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    lc = lc_dict(pb['t'], [b.name for b in pb['bands']], pb['y'], pb['dy'])
+    engines = [M.ShockCooling(redshift=0.004).engine_for(lc, priors=priors) for _ in range(ranks)]
+    assert len({id(e) for e in engines}) == ranks
+    samplers = [NativeSampler(e, nwalkers, 321) for e in engines]
+    ptrs = [s.mailbox_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.mailbox_connect(ranks, r, local_ptrs=ptrs)
+        # ranks emulated in ONE process share its host thread: an allocation (or free) made while another rank's
+        # launch waits for this rank would hold the launches back beyond the 0.5 s bound.  Size every buffer first.
+        s.set_state(x0)
+        s.run(100, nsteps, 'random', True)
+        s.set_state(x0)
+    for first, n in ((0, 4), (4, nsteps - 4)):          # two runs: the generations continue across runs
+        for s in samplers:
+            s.run_peers(first, n, 'random', True, asynchronous=True)
+        for s in samplers:
+            s.wait()
+    for s in samplers:
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain[4:]) and np.array_equal(lp, want_lp[4:])
+        assert np.array_equal(s.naccepted(), want_acc)
+
+
+@pytest.mark.parametrize('ranks', [2, 3])
+def test_peer_mailboxes_between_processes(ranks):
+    """Real processes, HIP IPC: tools/peer_ranks_check.py (every rank == the single-GPU chain, mailboxes connected)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'peer_ranks_check.py'), str(ranks), '48', '10'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['every_rank_equals_the_single_gpu_chain'] and line['peer_mailboxes_connected_on_every_rank']
