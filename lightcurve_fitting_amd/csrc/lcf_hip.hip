@@ -1129,12 +1129,23 @@ struct lcf_engine {
 
 namespace {
 
+// More than the default 64 KiB of dynamic LDS must be granted per kernel function, once.
+template <class K>
+inline void allow_lds(K kernel, size_t bytes) {
+    static bool raised = false;  // one flag per kernel type = per instantiation
+    if (bytes > 64 * 1024 && !raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+}
+
 template <int VARIANT, int MODE>
 void launch_points_v(const DevProblem& pb, dim3 grid, size_t lds, hipStream_t st, int w_lo, int n, const double* dP,
                      const double* coef, const double* lprior, const double2* therm, double* out0, double* out1) {
     const dim3 block(kBlock);
-#define LCF_GO(L, T) hipLaunchKernelGGL((k_points<VARIANT, MODE, L, T>), grid, block, lds, st, pb, w_lo, n, dP, coef, \
-                                        lprior, therm, out0, out1)
+#define LCF_GO(L, T) do { allow_lds(k_points<VARIANT, MODE, L, T>, lds);                                               \
+                          hipLaunchKernelGGL((k_points<VARIANT, MODE, L, T>), grid, block, lds, st, pb, w_lo, n, dP, coef, \
+                                             lprior, therm, out0, out1); } while (0)
     if (pb.tab_in_lds) {
         if (pb.use_therm) LCF_GO(true, true); else LCF_GO(true, false);
     } else {
@@ -1433,9 +1444,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_knots = companion ? pr->n_knots : 0;
     dp.has_priors = pr->priors ? 1 : 0;
     // LDS holds the first n_lds_tab samples of the table array: all of it, or the compressed levels only
+    int lds_tab_max = kLdsTabMax;
+    if (const char* env = std::getenv("LCF_LDS_TAB_MAX")) lds_tab_max = std::max(0, std::min(9500, std::atoi(env)));
     dp.n_lds_tab = NF > kLdsFiltMax ? 0
-                   : (int)htab.size() <= kLdsTabMax ? (int)htab.size()
-                   : (n_compressed > 0 && n_compressed <= kLdsTabMax) ? n_compressed : 0;
+                   : (int)htab.size() <= lds_tab_max ? (int)htab.size()
+                   : (n_compressed > 0 && n_compressed <= lds_tab_max) ? n_compressed : 0;
     // reddened weights are made while staging the FULL tables; when those do not fit nothing is staged and the
     // reddening is applied on the fly (slow path)
     dp.redden_slow = reddened && dp.n_lds_tab != (int)htab.size();
@@ -1878,6 +1891,8 @@ lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool f
     return LCF_OK;
 }
 
+constexpr size_t kLdsPerCU = 160 * 1024;
+
 size_t fused_lds_bytes(const lcf_engine* e) {
     return e->lds_bytes + kFusedScratch * sizeof(double) +
            (e->dp.use_therm ? (size_t)e->max_part_epochs * sizeof(double2) : 0);
@@ -1887,7 +1902,7 @@ bool fused_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_FUSED") != nullptr;
     const lcf_engine* e = s->e;
     return !disabled && s->half_step_kernel != LCF_HALF_STEP_PHASES && e->dp.tab_in_lds &&
-           fused_lds_bytes(e) <= 64 * 1024;
+           fused_lds_bytes(e) <= 64 * 1024;  // (measured with 160 KiB allowed: see DESIGN.md section 5 -- no gain)
 }
 
 // One launch for a whole half-step of a single-GPU run: commit half-step g_next - 1 (if pending), draw half-step
@@ -1907,8 +1922,9 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
     const dim3 grid((unsigned)((size_t)(hi - lo) * e->dp.n_parts + (foreign + kBlock / 64 - 1) / (kBlock / 64)));
     const size_t lds = fused_lds_bytes(e);
     double* lprior = ds.inline_finalize ? nullptr : s->lprior;  // the finalize launch of a sharded run reads it
-#define LCF_FUSED3(ND, V, T) hipLaunchKernelGGL((k_fused<ND, V, T>), grid, dim3(kBlock), lds, st, e->dp, ds, have_prev,  \
-                                                prev_row, draws, prev_draws, g, lo, hi, lprior)
+#define LCF_FUSED3(ND, V, T) do { allow_lds(k_fused<ND, V, T>, lds);                                                     \
+                                  hipLaunchKernelGGL((k_fused<ND, V, T>), grid, dim3(kBlock), lds, st, e->dp, ds,       \
+                                                     have_prev, prev_row, draws, prev_draws, g, lo, hi, lprior); } while (0)
 #define LCF_FUSED(ND)                                                                             \
     do {                                                                                          \
         if (e->dp.variant == 0) { if (e->dp.use_therm) LCF_FUSED3(ND, 0, true); else LCF_FUSED3(ND, 0, false); } \
@@ -1938,8 +1954,6 @@ size_t solo_lds_bytes(const lcf_engine* e) {
            (size_t)e->dp.n_filters * sizeof(FiltDesc) + (kSoloScratch + 4) * sizeof(double) +
            (e->dp.use_therm ? (size_t)e->dp.n_epochs * sizeof(double2) : 0);
 }
-
-constexpr size_t kLdsPerCU = 160 * 1024;
 
 bool solo_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_SOLO") != nullptr;
@@ -2686,7 +2700,8 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             }
         if (!have_next) break;
         const int parity = (int)((g + k) & 1);
-#define LCF_PM(V, L, T) hipLaunchKernelGGL((k_points_multi<V, L, T>), gp, bp, lds, st, ditems, parity)
+#define LCF_PM(V, L, T) do { allow_lds(k_points_multi<V, L, T>, lds);                                       \
+                             hipLaunchKernelGGL((k_points_multi<V, L, T>), gp, bp, lds, st, ditems, parity); } while (0)
         if (p0.variant == 0) {
             if (p0.tab_in_lds) { if (thermal) LCF_PM(0, true, true); else LCF_PM(0, true, false); }
             else { if (thermal) LCF_PM(0, false, true); else LCF_PM(0, false, false); }

@@ -31,3 +31,8 @@ print('one launch:', s.one_launch, 'points', len(t))
 x0 = truth * (1 + 0.05 * rng.standard_normal((1024, 5)))
 s.set_state(x0); s.run(0, 20, 'random', False); s.run(20, 100, 'random', False)
 print('us per step', s.last_run_ms() / 100 * 1e3)
+for kernel in ('fused', 'phases'):
+    s2 = NativeSampler(eng, 1024, 1)
+    print(kernel, '->', s2.set_half_step_kernel(kernel))
+    s2.set_state(x0); s2.run(0, 20, 'random', False); s2.run(20, 100, 'random', False)
+    print('   us per step', s2.last_run_ms() / 100 * 1e3)
