@@ -65,6 +65,10 @@ PEAK_HBM_GBS = 8000.
 # tools/isa_count.py; the float32 SED loop (k_sed<1>): 80 per quad
 VALU_PER_QUAD_F64 = 81
 VALU_PER_QUAD_F32 = 80
+# ... per data point on the interpolated path (variant 3: interval + Horner on 8 coefficients + one exponential +
+# residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (libm log + exp)
+VALU_PER_POINT_INTERP = 55
+VALU_PER_EPOCH_LOG = 140
 
 
 # =====================================================================================================================
@@ -82,8 +86,9 @@ def parse_args(argv=None):
                     help='mcmc: weak (1024 walkers per GPU, default) or strong (1024 in all); companion: strong (the '
                          '4096 walkers of configs[2] over the GPUs, default) or weak (512 per GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--variant', type=int, default=2,
-                    help='band sum: 2 = Gauss-compressed tables (default), 1 = the full tables, 0 = libm')
+    ap.add_argument('--variant', type=int, default=3,
+                    help='band sum: 3 = interpolated ln S(ln T) per filter where proved, Gauss-compressed tables elsewhere '
+                         '(default), 2 = Gauss-compressed tables, 1 = the full tables, 0 = libm')
     ap.add_argument('--collective', choices=['allgather', 'peers'], default='allgather',
                     help='N > 1: how the ranks exchange the rows of a half-step: one RCCL all-gather (default), or direct '
                          "stores into every rank's mailbox over IPC-mapped memory (no collective; experimental)")
@@ -250,17 +255,25 @@ def committed_pmc(tag):
 
 
 def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_quad, peak, alg_instr_per_eval,
-                   alg_bytes_per_eval, pmc_tag, waves_per_launch=None):
+                   alg_bytes_per_eval, pmc_tag, waves_per_launch=None, interp=None):
     """`achieved` / `frac`: lane-instructions of the band-sum loop the shipped algorithm executes per second, against
-    the vector-ALU issue peak -- a lower bound of what the kernel issues."""
+    the vector-ALU issue peak -- a lower bound of what the kernel issues.  `interp` = (points, epochs) per evaluation on
+    the interpolated path (variant 3), counted at their own instruction counts; `quads_per_eval` then covers only the
+    points that walk sample tables."""
     sec = kern_ms * 1e-3
-    shipped = evals_per_launch * quads_per_eval * valu_per_quad
+    per_eval = quads_per_eval * valu_per_quad
+    basis = (f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x {valu_per_quad} '
+             'vector-ALU instructions per quad')
+    if interp is not None:
+        per_eval += interp[0] * VALU_PER_POINT_INTERP + interp[1] * VALU_PER_EPOCH_LOG
+        basis += (f' + {interp[0]:.0f} interpolated points x {VALU_PER_POINT_INTERP} + {interp[1]:.0f} log-space thermal '
+                  f'states x {VALU_PER_EPOCH_LOG}')
+    shipped = evals_per_launch * per_eval
     achieved = shipped / sec / 1e12
     out = {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'Tinstr/s', 'frac': achieved / peak,
            'kernel': kernel, 'kernel_ms': kern_ms, 'evaluations_per_launch': evals_per_launch,
-           'basis': f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x '
-                    f'{valu_per_quad} vector-ALU instructions per quad (ISA count, tools/isa_count.py): the band-sum loop '
-                    'only, a lower bound of the instructions issued',
+           'basis': basis + ' (ISA counts, tools/isa_count.py): the likelihood loops only, a lower bound of the '
+                            'instructions issued',
            'algorithmic_speedup': evals_per_launch * alg_instr_per_eval / sec / 1e12 / peak,
            'algorithmic_speedup_note': "SURVEY 8d's instruction count of the reference's algorithm per second / the "
                                        'issue peak: exceeds 1 where the shipped algorithm needs fewer instructions '
@@ -298,11 +311,15 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
 
 
 def quads_per_evaluation(engine, truth):
-    """Quads of samples one likelihood evaluation walks at the parameters `truth` (the table level is chosen per point
-    from its temperature)."""
+    """(quads of samples one likelihood evaluation walks, points on the interpolated path) at the parameters `truth`:
+    the table level is chosen per point from its temperature."""
+    from lightcurve_fitting_amd.filters import INTERP_TMAX
     T, _ = engine.temperature_radius(np.asarray(truth, dtype=float))
-    compressed = getattr(engine, '_variant', 2) == 2
-    return float(np.sum(engine.tables.samples_at(engine.filt_idx, T[0], compressed)) / 4.)
+    variant = getattr(engine, '_variant', 3)
+    tabs, f = engine.tables, engine.filt_idx
+    interp = (variant == 3) & (T[0] >= tabs.itmin[f]) & (T[0] <= INTERP_TMAX)
+    n = np.where(interp, 0, tabs.samples_at(f, T[0], variant >= 2))
+    return float(np.sum(n) / 4.), int(np.sum(interp))
 
 
 def half_step_kernel_ms(engine, nwalkers, x0, seed, reps=1000):
@@ -413,12 +430,13 @@ def run_mcmc(args):
         # dominant kernel alone, at this rank's share of a half-step when the run is sharded over the GPUs
         per_rank = n_walkers // world
         kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7)
-        quads = quads_per_evaluation(engine, TRUTH)
+        quads, n_interp = quads_per_evaluation(engine, TRUTH)
         name = {'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
                         '+ likelihood + accept test)',
                 'fused': 'k_fused<5,1,true>', 'phases': 'k_step + k_points'}[used]
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, ALG_INSTR,
-                              ALG_BYTES, 'k_solo_mcmc', waves_per_launch=(per_rank // 2) * 8)
+                              ALG_BYTES, 'k_solo_mcmc', waves_per_launch=(per_rank // 2) * 8,
+                              interp=(n_interp, N_EPOCHS) if n_interp else None)
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -427,7 +445,8 @@ def run_mcmc(args):
                                    '500 synthetic epochs x 6 filters (UBVgri) = 3000 points, float64, '
                                    'device-resident stretch-move ensemble',
                        'walkers': n_walkers, 'points': ALG_POINTS, 'planck_samples_per_eval': ALG_SAMPLES,
-                       'planck_samples_executed_per_eval': 4 * quads, 'band_sum_variant': args.variant,
+                       'planck_samples_executed_per_eval': 4 * quads, 'points_interpolated_per_eval': n_interp,
+                       'band_sum_variant': args.variant,
                        'parallelism': f'walker-sharded x{world}' if world > 1 else 'single GPU'},
             'roofline': roof, 'collective': coll,
             'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None,
@@ -495,7 +514,7 @@ def run_companion(args):
     scaling = args.scaling or 'strong'
     nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
     engine = model.engine_for(lc, priors=priors)
-    engine._variant = 2
+    engine._variant = 3
     sampler = EnsembleSampler(nw, 8, engine, seed=SEED, collective=args.collective)
     x0 = companion_walkers(nw)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
@@ -504,13 +523,14 @@ def run_companion(args):
     if rank == 0:
         per_rank = nw // world
         kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7, reps=200)
-        quads = quads_per_evaluation(engine, COMPANION_TRUTH)
+        quads, n_interp = quads_per_evaluation(engine, COMPANION_TRUTH)
         full = int(engine.samples_per_eval)
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
         name = {'solo': 'k_solo<8,1,true,4> (one 1024-thread workgroup per proposal)', 'fused': 'k_fused<8,1,true>',
                 'phases': 'k_step + k_points'}[used]
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr,
-                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 16)
+                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 16,
+                              interp=(n_interp, 1000) if n_interp else None)
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -518,7 +538,7 @@ def run_companion(args):
                'config': {'workload': 'BASELINE configs[2]: CompanionShocking + SiFTO template, 4096 walkers, 8 filters '
                                       'x 1000 epochs = 8000 points, float64, walkers sharded over the GPUs',
                           'walkers': nw, 'points': 8000, 'planck_samples_per_eval': full,
-                          'planck_samples_executed_per_eval': 4 * quads},
+                          'planck_samples_executed_per_eval': 4 * quads, 'points_interpolated_per_eval': n_interp},
                'roofline': roof, 'collective': coll,
                'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None}
         if world == 1 and not args.no_cpu_baseline:
@@ -560,6 +580,8 @@ def run_population(args):
             problems.append((model, None, priors))
         x0[k] = walkers
     pop = PopulationSampler(problems, nw, seed=SEED, device=local_rank)
+    for k in pop.indices:
+        pop[k].engine.set_variant(args.variant)
     pop.run_mcmc(x0, args.warmup, store=False)
     torch.cuda.synchronize()
     if dist is not None:
@@ -572,13 +594,14 @@ def run_population(args):
     elapsed = max_over_ranks(dist, time.perf_counter() - t0)
     if rank == 0:
         eng = pop[pop.indices[0]].engine
-        eng._variant = 2
-        quads = quads_per_evaluation(eng, first_truth)
+        eng._variant = args.variant
+        quads, n_interp = quads_per_evaluation(eng, first_truth)
         pair_ms = pop.last_run_ms / (2 * args.steps)    # one k_step_multi + one k_points_multi per half-step
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
         roof = roofline_block('k_step_multi + k_points_multi (the two launches of a half-step of all 32 transients of this '
                               'GPU; the likelihood launch dominates)', pair_ms, 32 * nw // 2, quads, VALU_PER_QUAD_F64,
-                              PEAK_FP64_TINSTR, alg_instr, ALG_BYTES, 'population')
+                              PEAK_FP64_TINSTR, alg_instr, ALG_BYTES, 'population',
+                              interp=(n_interp, 100) if n_interp else None)
         out = {'metric': 'walker-steps/sec (population of independent ensembles)',
                'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,

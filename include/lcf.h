@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 5
+#define LCF_ABI_VERSION 6
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -112,6 +112,17 @@ typedef struct lcf_problem {
     const double* htab_a;     /* [htab_off[n_filters]] */
     const double* htab_w;     /* [htab_off[n_filters]] */
     const double* htab_tmin;  /* [n_filters] kK */
+    /* Optional third level (NULL = none; not for LCF_MODEL_SHOCK_COOLING3): the band sum of every filter as a FUNCTION
+     * of temperature -- ln S_f(T) as piecewise polynomials of degree 7 in u = ln T on itab_m equal intervals of width
+     * itab_h from itab_u0 = ln(first temperature in kK), 8 monomial coefficients in s in [-1, 1] per interval, highest
+     * power first -- valid for T >= itab_tmin[i] up to the last interval's end.  The host packer builds and proves them
+     * (filters.interp_planck_table).  With it the engine evaluates a data point by one lookup, 7 fused multiply-adds
+     * and one exponential wherever the point's temperature is inside the range; elsewhere it walks the sample tables. */
+    const double* itab_coef;  /* [n_filters][itab_m][8] */
+    const double* itab_tmin;  /* [n_filters] kK; +inf = no interpolant for this filter */
+    int32_t itab_m;
+    int32_t reserved2;
+    double itab_u0, itab_h;
     const int32_t* filt_kasen_par; /* [n_filters] or NULL */
     const int32_t* filt_sifto_par; /* [n_filters] or NULL */
     const int32_t* filt_dt_par;    /* [n_filters] or NULL */

@@ -50,7 +50,9 @@ struct PriorDev {
 // Tables of one filter inside `tab` (offsets / counts in samples, counts padded to quads): the full table and up to
 // two Gauss-compressed companions, "cool" (valid for 1/T <= inv_tmin) and the shorter "hot" (1/T <= inv_tmin2).
 struct FiltDesc {
-    int off, cnt, coff, ccnt, hoff, hcnt, pad0, pad1;
+    int off, cnt, coff, ccnt, hoff, hcnt;
+    float u_min;   // ln of the temperature from which the filter's interpolant (below) is proved; +inf: none
+    int ioff;      // its coefficients in the interpolant array, in doubles
     double inv_tmin, inv_tmin2;  // 0 = that level does not exist
 };
 static_assert(sizeof(FiltDesc) == 48, "three double2 per filter in LDS");
@@ -62,7 +64,16 @@ struct DevProblem {
     int n_epochs, use_therm, use_ctab, n_tab;
     int n_lds_tab;    // samples of `tab` staged in LDS: all, or the compressed levels only (they come first)
     int redden_slow;  // ShockCooling3 whose tables do not fit in LDS: reddening applied per sample from global memory
-    int n_parts, cpb, pad2, pad3;  // workgroups per walker ("parts"), most point chunks in one part
+    int n_parts, cpb;  // workgroups per walker ("parts"), most point chunks in one part
+    // Third table level: ln S_f(T) of every filter as piecewise polynomials of degree 7 in u = ln T on itab_m equal
+    // intervals from itab_u0 (packed and proved by the host, filters.interp_planck_table).  With it a model whose
+    // thermal state is known in log space costs one lookup + 7 FMA + ONE exponential per data point.
+    int use_itab, itab_m;
+    int itab_uniform;     // every filter's interpolant is proved from the first interval on (no per-filter threshold)
+    int n_itab_lds;       // doubles of `itab` staged in LDS behind the filter descriptors (all of it, or 0)
+    int stage_d2;         // double2 entries of the staged region: tables + descriptors + interpolants
+    double itab_u0, itab_inv_h, itab_umax;
+    const double* itab;   // [n_filters][itab_m][8], highest power first
     int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs ...
     int part_ep0[kMaxParts + 1];    // ... namely the epochs [part_ep0[j], part_ep0[j+1]) (when use_therm)
     int pad4[2];
@@ -170,6 +181,35 @@ __device__ inline double div_pos(double n, double d) {
     return fma(fma(-d, q, n), r, q);
 }
 
+// Natural logarithm for the per-walker / per-epoch model arithmetic of the log-space state: libm's costs ~90 mostly
+// dependent FP64 instructions, this one ~32 with an error of ~1 ulp.  x = m 2^e with m in [sqrt(1/2), sqrt(2));
+// ln m = 2 atanh(s), s = (m - 1)/(m + 1), |s| <= 0.1716: odd series through s^21 (truncation < 3e-17 relative);
+// e ln 2 added as a hi/lo pair.  Subnormal arguments included; flog(+inf) = +inf; NaN for x <= 0 and NaN (no caller
+// uses the logarithm of a non-positive number).
+__device__ inline double flog(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.7071067811865476;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = div_pos(m - 1., m + 1.);
+    const double z = s * s;
+    double p = 1. / 21.;
+    p = fma(p, z, 1. / 19.);
+    p = fma(p, z, 1. / 17.);
+    p = fma(p, z, 1. / 15.);
+    p = fma(p, z, 1. / 13.);
+    p = fma(p, z, 1. / 11.);
+    p = fma(p, z, 1. / 9.);
+    p = fma(p, z, 1. / 7.);
+    p = fma(p, z, 1. / 5.);
+    p = fma(p, z, 1. / 3.);
+    const double lnm = fma(s * z, p + p, s + s);
+    const double ef = (double)e;
+    const double r = fma(ef, 0.6931471803691238, fma(ef, 1.9082149292705877e-10, lnm));  // ln 2 = hi (32 bits) + lo
+    return x > 0. ? (x < INFINITY ? r : x) : __longlong_as_double(0x7ff8000000000000LL);
+}
+
 // Four samples share one division:  n1/d1 + n2/d2 = (n1 d2 + n2 d1)/(d1 d2).
 // Tables are padded to a multiple of four samples with zero weights (contribute exactly 0).
 template <class TabPtr>
@@ -221,12 +261,20 @@ __device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const E
 //   ShockCooling4:  c[1] = T_col_br/k_B, c[2] = L_br, c[3] = t_br, c[4] = t_tr
 //   Companion:      c[1] = T coefficient, c[2] = R^2 coefficient, c[3] = t_peak, c[4] = stretch, c[5] = shock factor
 //   Blackbody:      c[1] = T, c[2] = R^2
+//   Every model but ShockCooling3 also leaves the logarithms of its two amplitudes for the log-space thermal state
+//   (thermal_state_log):  c[6] = ln(temperature coefficient),  c[7] = ln(coefficient of R_bb^2) -- for the
+//   shock-cooling family ln(c3^2 L coefficient), so that ln R_bb^2 = c[7] + ... - 4 ln T -- or NaN where the amplitude
+//   is not positive and finite (the linear-space rules of thermal_state then decide).
 // ---------------------------------------------------------------------------------------------------------------
 // `lq[d]` = log(p[d]) for d < n_par (may be NaN/-inf where p[d] <= 0: only used when the parameter is positive).
+// `log_only`: the caller's thermal states stay in log space (thermal_state_log of a power-law model): the linear
+// amplitudes c[1], c[2] -- one exponential each -- are then not needed and are left NaN.
 __device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p,
-                                           const double* __restrict__ lq, double* __restrict__ c) {
+                                           const double* __restrict__ lq, double* __restrict__ c,
+                                           bool log_only = false) {
     const double* k = pb.consts;
     for (int i = 0; i < kNCoef; ++i) c[i] = 0.;
+    if (pb.model != kShockCooling3) c[6] = c[7] = qnan();
     switch (pb.model) {
         case kShockCooling:
         case kShockCooling3: {  // models.py:260-267; ShockCooling3 (models.py:493-495): + distance and reddening
@@ -242,10 +290,16 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             if (v > 0. && M > 0. && f > 0. && R > 0. && v < 1e100 && M < 1e100 && f < 1e100 && R < 1e100) {
                 // all bases positive: every power() is a plain power; share the four logarithms
                 const double lv = lq[0], lM = lq[1], lf = lq[2], lR = lq[3];
-                c[1] = (T0 * ratio / kKB) * exp(eps1 * (2. * lv - lf) + 0.25 * lR);
-                c[2] = (L0 * A) * exp(-eps2 * (lv - lf) + 2. * lv + lR);
+                const double a1 = eps1 * (2. * lv - lf) + 0.25 * lR, a2 = -eps2 * (lv - lf) + 2. * lv + lR;
+                const bool skip = log_only && pb.model == kShockCooling;
+                c[1] = skip ? qnan() : (T0 * ratio / kKB) * exp(a1);
+                c[2] = skip ? qnan() : (L0 * A) * exp(a2);
                 c[3] = a > 0. ? alpha * (k[11] - 0.5 * (lM - lv)) : qnan();  // k[11] = ln(a / 19.5), set at create
                 c[4] = 0.;
+                if (pb.model == kShockCooling) {  // k[9] = ln(T0 ratio / k_B), k[10] = ln(c3^2 L0 A), set at create
+                    c[6] = k[9] + a1;
+                    c[7] = k[10] + a2;
+                }
                 break;
             }
             const double Lc = L0 * pw(v / f, -eps2) * v * v * R;  // L_RW = Lc * |t|^(-2 eps2)
@@ -255,6 +309,10 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[2] = Lc * A;
             c[3] = g > 0. ? alpha * log(g) : qnan();
             c[4] = (Lc >= 0.) ? 0. : 1.;
+            if (pb.model == kShockCooling) {
+                c[6] = (c[1] > 0. && c[1] < INFINITY) ? log(c[1]) : qnan();
+                c[7] = (c[2] >= 0. && c[2] < INFINITY) ? log(kC3sq * c[2]) : qnan();
+            }
             break;
         }
         case kShockCooling2: {  // models.py:403-406
@@ -264,6 +322,8 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[1] = p[0];
             c[2] = p[1] * 1e42;
             c[3] = g > 0. ? alpha * log(g) : qnan();
+            c[6] = (c[1] > 0. && c[1] < INFINITY) ? lq[0] : qnan();
+            c[7] = (c[2] >= 0. && c[2] < INFINITY) ? log(kC3sq * c[2]) : qnan();
             break;
         }
         case kShockCooling4: {  // models.py:584-587 (quirks kept: no kappa in t_br, right-associative ** chain)
@@ -291,12 +351,16 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[0] = p[0];
             if (a13 > 0. && Mv > 0. && a13 < 1e8 && a13 > 1e-8 && Mv < 1e100) {
                 const double la = lq[1], lm = pb.model == kCompanion3 ? 0. : lq[2];
-                c[1] = 25. * exp((36. * la + lm) * (1. / 144.));
-                c[2] = 7.29 * exp(lm * (2. / 9.));
+                c[1] = log_only ? qnan() : 25. * exp((36. * la + lm) * (1. / 144.));
+                c[2] = log_only ? qnan() : 7.29 * exp(lm * (2. / 9.));
+                c[6] = 3.2188758248682006 + (36. * la + lm) * (1. / 144.);  // ln 25
+                c[7] = 1.9865035460205669 + lm * (2. / 9.);                  // ln 7.29
             } else {
                 c[1] = 25. * pw(pow(a13, 36.) * Mv, 1. / 144.);
                 const double rc = 2.7 * pw(Mv, 1. / 9.);
                 c[2] = rc * rc;
+                c[6] = (c[1] > 0. && c[1] < INFINITY) ? log(c[1]) : qnan();
+                c[7] = (c[2] >= 0. && c[2] < INFINITY) ? log(c[2]) : qnan();
             }
             c[3] = p[3];
             c[4] = p[4];
@@ -320,7 +384,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
 // Convenience for one-thread-per-walker callers: logarithms computed in place.
 __device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p, double* __restrict__ c) {
     double lq[kMaxDim];
-    for (int d = 0; d < pb.n_par; ++d) lq[d] = log(p[d]);
+    for (int d = 0; d < pb.n_par; ++d) lq[d] = flog(p[d]);  // (the serial heads of the sampler take the same logarithm)
     walker_coefficients(pb, p, lq, c);
 }
 
@@ -458,6 +522,91 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
             break;
         default:
             break;
+    }
+}
+
+// The same thermal state in LOG space, for the interpolated band sums (DevProblem::itab): a pair (x, p) with
+//   x > 0:            x = ln T_K (between the interpolants' ln 2 kK and ln 256 kK), p = ln R_bb^2
+//   sign bit of x set: x = -1/T_K (-0.0 where the band integral vanishes), p = R_bb^2 (0, or NaN to propagate) -- the
+//                      linear-space state, for the sample-table band sum.
+// Power-law models never leave log space: ln T = c[6] + eT ln t and ln R_bb^2 = c[7] + eL ln t - E - 4 ln T come from
+// ONE logarithm and at most one exponential per epoch.  The special cases follow thermal_state rule for rule.
+// Logarithm / exponential of the per-epoch state: libm.  Measured at 1024 walkers x 3000 points (walker-steps/s):
+// libm + libm 3.73e7, libm log + table exponential 3.67e7, flog + table exponential 3.20e7 -- the short versions'
+// constants are hoisted out of the epoch loop into registers and push the point loop into spills.
+#ifndef LCF_TLOG
+#define LCF_TLOG 0   // 1 = flog, 0 = libm
+#endif
+#ifndef LCF_TEXP
+#define LCF_TEXP 0   // 1 = through the 2^(j/256) table, 0 = libm
+#endif
+__device__ inline double tlog(double x) { return LCF_TLOG ? flog(x) : log(x); }
+
+__device__ inline void encode_linear(double invT, double pref, double& x, double& p) {
+    x = -invT;
+    p = pref;
+}
+
+__device__ inline void thermal_state_log(const DevProblem& pb, const double* __restrict__ c, double t_in, double& x,
+                                         double& p, const ExpTab et) {
+    const double* k = pb.consts;
+    const double t = t_in - c[0];
+    x = -0.;
+    p = 0.;
+    double u = qnan(), lp = 0.;  // ln T, ln R_bb^2 when both exist
+    switch (pb.model) {
+        case kShockCooling:
+        case kShockCooling2: {
+            const double eps1 = k[3], eps2 = k[4], alpha = k[2];
+            if (t > 0.) {
+                const double lt = tlog(t);
+                // (the exponential through the 2^(j/256) table: same arithmetic whether `et` points to LDS or memory)
+                const double E = !(c[3] == c[3]) ? 0.
+                                 : LCF_TEXP ? exp_scaled<true>(fma(alpha, lt, c[3]) * kInvLn2N, et)
+                                            : exp(fma(alpha, lt, c[3]));
+                const double lL = fma(-2. * eps2, lt, c[7]) - E;  // ln(c3^2 L)
+                if (!(lL == lL)) {
+                    p = qnan();          // L < 0 or NaN
+                    return;
+                }
+                u = fma(2. * eps1 - 0.5, lt, c[6]);
+                lp = fma(-4., u, lL);
+            } else {
+                if (t < 0. && c[4] != 0.) p = qnan();  // sqrt(L) with L < 0 before the explosion
+                return;
+            }
+            break;
+        }
+        case kCompanion:
+        case kCompanion2:
+        case kCompanion3: {
+            if (!(t > 0.)) return;
+            const double lt = tlog(t);
+            if (!(lt > -9.5916 && lt < 10.06)) return;   // power(t, -74) over- / underflows: zero band integral
+            u = fma(-74. / 144., lt, c[6]);
+            lp = fma(14. / 9., lt, c[7]);
+            if (!(lp == lp)) u = qnan();                   // (M v^7 <= 0: R = 0 -> nothing)
+            break;
+        }
+        default: {  // ShockCooling4, Blackbody: linear-space state, then two logarithms
+            double T, invT, pref;
+            thermal_state(pb, c, t_in, T, invT, pref);
+            if (T > 0. && pref > 0. && pref < INFINITY) {
+                u = log(T);
+                lp = log(pref);
+            } else {
+                encode_linear(invT, pref, x, p);
+                return;
+            }
+            break;
+        }
+    }
+    if (!(u == u) || !(u < 34.538776394910684)) return;  // T <= 0, NaN or >= 1e15 kK: zero band integral
+    if (u >= pb.itab_u0 && u <= pb.itab_umax) {
+        x = u;   // (> 0: the interpolants start at 2 kK)
+        p = lp;
+    } else if (u > -50.) {  // outside the interpolants' range: the sample tables, in linear space
+        encode_linear(exp(-u), exp(lp), x, p);
     }
 }
 

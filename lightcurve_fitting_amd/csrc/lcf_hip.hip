@@ -37,6 +37,9 @@
 #ifndef LCF_KPRE
 #define LCF_KPRE 4   // chunks of points whose operands are fetched together
 #endif
+#ifndef LCF_KPRE_SOLO
+#define LCF_KPRE_SOLO 2  // the same in the one-workgroup-per-proposal kernel (4: 3.73e7 walker-steps/s, 3: 3.74e7, 2: 3.78e7)
+#endif
 #ifndef LCF_WAVES
 #define LCF_WAVES 4  // occupancy the register allocator is asked to keep (waves per SIMD)
 #endif
@@ -98,23 +101,83 @@ __device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use
     return VARIANT == 0 ? band_sum_ref(tab, cnt, invT) : band_sum_fast(tab, cnt, invT, et);
 }
 
+// ln S_f(e^u) from the filter's interpolant: interval of u, then Horner's rule on 8 coefficients (four 16-byte reads).
+// `lds_at` >= 0: the interpolants are staged in LDS at that byte offset of the workgroup's dynamic LDS (the address is
+// formed from the LDS symbol itself, so that the reads are ds_read_b128 and not generic-pointer loads); < 0: global.
+__device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int lds_at, int ioff, double u) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const double r = (u - pb.itab_u0) * pb.itab_inv_h;
+    const int j = min(max((int)r, 0), pb.itab_m - 1);
+    const double s = fma(r, 2., -(double)(2 * j + 1));   // in [-1, 1]
+    double2 q0, q1, q2, q3;
+    if (lds_at >= 0) {
+        const double2* q = reinterpret_cast<const double2*>(smem + lds_at) + (ioff + 8 * j) / 2;
+        q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    } else {
+        const double2* q = reinterpret_cast<const double2*>(pb.itab + ioff + 8 * j);
+        q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    }
+    double g = fma(q0.x, s, q0.y);
+    g = fma(g, s, q1.x);
+    g = fma(g, s, q1.y);
+    g = fma(g, s, q2.x);
+    g = fma(g, s, q2.y);
+    g = fma(g, s, q3.x);
+    return fma(g, s, q3.y);
+}
+
 // Everything one lane does for its data point after the thermal state (1/T, R_bb^2): band sum(s) -> template term.
 // STAGED: the band tables (or their compressed levels) are in LDS; the on-the-fly reddening fall-back exists only in
 // the unstaged instantiations, so that it costs the staged kernels no registers.
-template <int VARIANT, bool STAGED, class TabPtr>
+template <int VARIANT, bool STAGED>
 __device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
-                                     const double* __restrict__ p, double t_in, int filt, const TabSel<TabPtr> ts,
-                                     const ExpTab et, double invT, double pref) {
-    double S = 0.;
-    if (!STAGED && invT > 0. && pb.redden_slow) {
+                                     const double* __restrict__ p, double t_in, int filt, const double2* tbase,
+                                     const FiltDesc* fdesc, const ExpTab et, double invT, double pref, int itab_at) {
+    double S = 0., yfit;
+    const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt;  // the filter's descriptor: three 16-byte reads
+    // Log-space state (x = ln T > 0, pref = ln R_bb^2; see thermal_state_log): the interpolant if every point of the
+    // wave is inside its filter's proved range -- a per-wave choice, like the fast / safe band sums, so that a walker's
+    // result never depends on how walkers are batched -- else the sample tables after one exponential each.
+    bool by_table = false;
+    int ioff = filt * pb.itab_m * 8;
+    if (VARIANT != 0 && pb.use_itab) {
+        const bool log_form = __double2hiint(invT) >= 0;   // (-0.0 and -1/T have the sign bit set)
+        bool inside = log_form;
+        if (!pb.itab_uniform || pb.model == kShockCooling4) {
+            const long long fmeta = __double_as_longlong(fd[1].y);   // {float u_min, int ioff} of the filter's interpolant
+            ioff = (int)(fmeta >> 32);
+            // (ShockCooling4 also needs the band sum at 0.74 T)
+            const double u_low = pb.model == kShockCooling4 ? invT - 0.3011050927839216 : invT;
+            inside = log_form && u_low >= (double)__int_as_float((int)fmeta);
+        }
+        if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+            by_table = true;
+        } else if (log_form) {  // a mixed wave: back to linear space
+            invT = exp(-invT);
+            pref = exp(pref);
+        } else {
+            invT = -invT;
+        }
+    }
+    if (by_table) {
+        double L = interp_log_band_sum(pb, itab_at, ioff, invT);
+        if (pb.model == kShockCooling4)  // min(blackbody, suppressed blackbody at 0.74 T), models.py:629-631
+            L = fmin(L, interp_log_band_sum(pb, itab_at, ioff, invT - 0.3011050927839216) + 1.2044203711356864);  // ln 0.74, -4 ln 0.74
+        yfit = exp_scaled<true>((L + pref) * kInvLn2N, et);
+    } else if (!STAGED && invT > 0. && pb.redden_slow) {
         // ShockCooling3 through tables too long for LDS: the walker's reddening is applied sample by sample to the
         // full table in global memory (libm; a fall-back, not a fast path)
-        const int off = (int)ts.full, cnt = (int)(ts.full >> 32);
+        const long long full = __double_as_longlong(fd[0].x);
+        const int off = (int)full, cnt = (int)(full >> 32);
         for (int k = 0; k < cnt; ++k) {
             const double2 aw = pb.tab[off + k];
             S += aw.y * exp2(-c[6] * pb.tab_ext[off + k]) / expm1(aw.x * invT);
         }
     } else if (invT > 0.) {
+        const double2 d0 = fd[0], d1 = fd[1], d2 = fd[2];
+        const TabSel<const double2*> ts{tbase, __double_as_longlong(d0.x), __double_as_longlong(d0.y),
+                                        __double_as_longlong(d1.x), d2.x, d2.y, pb.tab,
+                                        STAGED ? pb.n_lds_tab : 0x7fffffff};
         S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT, et);
         if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
             const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT * (1. / 0.74), et);
@@ -122,7 +185,7 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
         }
     }
     // pref may be NaN (propagates) or 0 with 1/T == 0.
-    double yfit = (pref != pref) ? pref : pref * S;
+    if (!by_table) yfit = (pref != pref) ? pref : pref * S;
     if (pb.model == kShockCooling3) yfit *= c[5];  // models.py:495
     if (pb.model >= kCompanion && pb.model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
         const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
@@ -142,13 +205,16 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
 __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_lo, int n_w,
                                                     const double* __restrict__ coef,
                                                     const double* __restrict__ lprior, int skip_excluded,
-                                                    double2* __restrict__ therm) {
+                                                    double2* __restrict__ therm, int log_state) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_w * pb.n_epochs) return;
     const int w = w_lo + idx / pb.n_epochs, ep = idx % pb.n_epochs;
     if (skip_excluded && lprior[w] == -INFINITY) return;
     double T, invT, pref;
-    thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, invT, pref);
+    if (log_state)
+        thermal_state_log(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], invT, pref, ExpTab{pb.exp2tab});
+    else
+        thermal_state(pb, coef + (size_t)w * kNCoef, pb.epoch_t[ep], T, invT, pref);
     therm[(size_t)w * pb.n_epochs + ep] = make_double2(invT, pref);
 }
 
@@ -164,6 +230,10 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
         double2* lfd = ltab + pb.n_lds_tab;
         const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
         for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
+        // ... and the filters' interpolants behind those
+        double2* lit = lfd + 3 * pb.n_filters;
+        const double2* git = reinterpret_cast<const double2*>(pb.itab);
+        for (int k = t; k < pb.n_itab_lds / 2; k += nt) lit[k] = git[k];
         if (pb.model == kShockCooling3 && !pb.redden_slow) {
             for (int k = t; k < pb.n_lds_tab; k += nt) {
                 double2 aw = pb.tab[k];
@@ -179,16 +249,17 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
 // The points of part `part` for one walker: parameters p, coefficients c (global or LDS), thermal states
 // th[pt_epoch - e_off] when THERM.  MODE 0: returns this thread's share of chi^2;  MODE 1: y_fit -> out0[row][orig];
 // MODE 2: T, R_bb -> out0, out1.
-template <int VARIANT, int MODE, bool LDS_TAB, bool THERM, int KPRE_POINTWISE = 2>
+template <int VARIANT, int MODE, bool LDS_TAB, bool THERM, int KPRE_POINTWISE = 0>
 __device__ inline double points_loop(const DevProblem& pb, int part, size_t row, const double* __restrict__ p,
                                      const double* __restrict__ c, const double2* __restrict__ th_base, int e_off,
                                      const double2* tbase, const FiltDesc* fdesc, const ExpTab et,
-                                     double* __restrict__ out0, double* __restrict__ out1, int tid = threadIdx.x) {
+                                     double* __restrict__ out0, double* __restrict__ out1, int tid = threadIdx.x,
+                                     int itab_at = -1) {
     double term = 0.;  // `tid`: this thread's index among the kBlock threads that walk the part
     const int p0 = part_entry(pb.part_start, part), p1 = part_entry(pb.part_start, part + 1);  // this part's points
     // chunks whose operands are fetched together, before any band sum starts (fewer when the thermal state is computed
     // per point: that code needs the registers)
-    constexpr int kPre = THERM ? LCF_KPRE : KPRE_POINTWISE;
+    constexpr int kPre = THERM ? (KPRE_POINTWISE == 1 ? LCF_KPRE_SOLO : LCF_KPRE) : 1;
     for (int k0 = 0; k0 * kBlock < p1 - p0; k0 += kPre) {
         int idx[kPre], filt[kPre];
         double tin[kPre], yv[kPre], idy[kPre];
@@ -210,16 +281,12 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
         for (int u = 0; u < kPre; ++u) {
             const int i = idx[u];
             if (i < 0) continue;
-            // the filter's descriptor as three 16-byte reads (LDS when the tables are staged)
-            const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt[u];
-            const double2 d0 = fd[0], d1 = fd[1], d2 = fd[2];
-            const TabSel<const double2*> ts{tbase, __double_as_longlong(d0.x), __double_as_longlong(d0.y),
-                                            __double_as_longlong(d1.x), d2.x, d2.y, pb.tab,
-                                            LDS_TAB ? pb.n_lds_tab : 0x7fffffff};
             double invT, pref, Tk = 0.;
             if (THERM && MODE != 2) {
-                invT = th[u].x;
+                invT = th[u].x;   // (the log-space pair of thermal_state_log when the engine interpolates)
                 pref = th[u].y;
+            } else if (MODE != 2 && VARIANT != 0 && pb.use_itab) {
+                thermal_state_log(pb, c, tin[u], invT, pref, et);
             } else {
                 thermal_state(pb, c, tin[u], Tk, invT, pref);
             }
@@ -230,7 +297,7 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 out1[j] = sqrt(pref);
                 continue;
             }
-            const double yfit = point_model<VARIANT, LDS_TAB>(pb, c, p, tin[u], filt[u], ts, et, invT, pref);
+            const double yfit = point_model<VARIANT, LDS_TAB>(pb, c, p, tin[u], filt[u], tbase, fdesc, et, invT, pref, itab_at);
             if (MODE == 0) {  // models.py:121-135
                 const double r = yv[u] - yfit;
                 if (pb.use_sigma) {
@@ -286,9 +353,12 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
 
     const double2* tbase = LDS_TAB ? (const double2*)ltab : pb.tab;
     const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab) : pb.f_desc;
+    // byte offset of the staged interpolants in the dynamic LDS (behind the tables and descriptors), or -1
+    const int itab_at = (LDS_TAB && pb.n_itab_lds > 0)
+                            ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
         pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
-        tbase, fdesc, ExpTab{exptab}, out0, out1);
+        tbase, fdesc, ExpTab{exptab}, out0, out1, threadIdx.x, itab_at);
     if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * part_stride(pb) + part);
 }
 
@@ -642,11 +712,11 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
             }
             return;
         }
-        const double lg = log(arg);  // one logarithm per lane, all at once
+        const double lg = flog(arg);  // one logarithm per lane, all at once
 #pragma unroll
         for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
         double c[kNCoef];
-        walker_coefficients(pb, q, lq, c);
+        walker_coefficients(pb, q, lq, c, pb.use_itab != 0 && pb.variant != 0);
         // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
         double lpr = 0.;
         if (pb.has_priors) {
@@ -732,7 +802,10 @@ __device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int
     const int ep_end = min((ec + 1) * kBlock, pb.n_epochs);
     for (int e2 = ep; e2 < ep_end; e2 += blockDim.x) {
         double T, invT, pref;
-        thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, invT, pref);
+        if (pb.use_itab && pb.variant != 0)
+            thermal_state_log(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], invT, pref, ExpTab{pb.exp2tab});
+        else
+            thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, invT, pref);
         therm[(size_t)i * pb.n_epochs + e2] = make_double2(invT, pref);
     }
 }
@@ -777,7 +850,9 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     double* red = exptab + kExpTabSize;
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
-    double* sc = reinterpret_cast<double*>(ltab + pb.n_lds_tab + 3 * pb.n_filters);
+    const int itab_at = pb.n_itab_lds > 0
+                            ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+    double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);
     double* sq = sc + kNCoef + 2;
     double2* lth = reinterpret_cast<double2*>(sc + kFusedScratch);
     const int tid = threadIdx.x;
@@ -810,13 +885,16 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
         const int e1 = part_entry(pb.part_ep0, part + 1);
         for (int e = e0 + tid; e < e1; e += kBlock) {
             double T, invT, pref;
-            thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
+            if (VARIANT != 0 && pb.use_itab)
+                thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
+            else
+                thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
             lth[e - e0] = make_double2(invT, pref);
         }
     }
     if (THERM || reddened) __syncthreads();
     const double term = points_loop<VARIANT, 0, true, THERM>(pb, part, 0, sq, cs, lth, e0, ltab, fdesc, ExpTab{exptab},
-                                                             nullptr, nullptr);
+                                                             nullptr, nullptr, threadIdx.x, itab_at);
     const double psum = store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
     if (sm.n_peers > 0 && tid == 0) mbox_post(sm, g, i, part, part_stride(pb), psum);  // straight into every rank's mailbox
 }
@@ -857,7 +935,9 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
-    double* sc = reinterpret_cast<double*>(ltab + pb.n_lds_tab + 3 * pb.n_filters);  // coefficients, then log-prior
+    const int itab_at = pb.n_itab_lds > 0
+                            ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+    double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);  // coefficients, then log-prior
     double* sq = sc + kNCoef + 2;                                           // the proposal
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
     double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
@@ -893,12 +973,12 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         LCF_STAMP(0, 2);
-        const double lg = log(arg);
+        const double lg = flog(arg);
 #pragma unroll
         for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
         LCF_STAMP(0, 3);
         double c[kNCoef];
-        walker_coefficients(pb, q, lq, c);
+        walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
         LCF_STAMP(0, 4);
         double lpr = 0.;
         if (pb.has_priors) {
@@ -953,7 +1033,10 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
 #pragma unroll 1
             for (int e = e0 + ltid; e < e1; e += kBlock) {
                 double T, invT, pref;
-                thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
+                if (pb.use_itab)
+                    thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
+                else
+                    thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
                 lth[e] = make_double2(invT, pref);
             }
         }
@@ -961,7 +1044,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
         LCF_STAMP(0, 7);
         if (part < pb.n_parts)
             term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
-                                                           nullptr, nullptr, ltid);
+                                                           nullptr, nullptr, ltid, itab_at);
         LCF_STAMP(0, 8);
         LCF_STAMP(1, 12);
         const double ws = wave_sum(term);
@@ -1075,7 +1158,7 @@ struct lcf_engine {
     int* d_tab_off = nullptr;   // per filter: (offset, count) of the full table in the device table
     int* d_ctab_off = nullptr;  // per filter: (offset, count) of the compressed table
     double* d_ctmin = nullptr;
-    bool have_ctab = false;
+    bool have_ctab = false, have_itab = false;
     int max_part_epochs = 0;  // most distinct epochs in one part (LDS need of the fused sampler kernel)
     // workspace for n walkers
     int64_t cap = 0;
@@ -1162,7 +1245,7 @@ void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const
     if (pb.use_therm && do_thermal) {
         const long long total = (long long)n * pb.n_epochs;
         hipLaunchKernelGGL(k_thermal, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pb, w_lo, n,
-                           coef, lprior, MODE == 0 ? 1 : 0, therm);
+                           coef, lprior, MODE == 0 ? 1 : 0, therm, (MODE != 2 && pb.variant != 0 && pb.use_itab) ? 1 : 0);
     }
     const dim3 grid((unsigned)((size_t)n * pb.n_parts));
     if (pb.variant == 0)
@@ -1320,6 +1403,18 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     // (a reddened model reweights the samples per walker: the compressed tables do not apply)
     const bool have_ctab = pr->ctab_off && pr->ctab_a && pr->ctab_w && pr->ctab_tmin && !reddened;
     const bool have_htab = have_ctab && pr->htab_off && pr->htab_a && pr->htab_w && pr->htab_tmin;
+    const bool have_itab = !reddened && pr->itab_coef && pr->itab_tmin && pr->itab_m > 0 && pr->itab_h > 0.;
+    if (have_itab) {
+        if (pr->itab_m > 4096 || !(pr->itab_u0 > 0.) || !std::isfinite(pr->itab_h))
+            return bail(fail(LCF_ERR_INVALID_ARGUMENT, "interpolants: 0 < itab_m <= 4096, itab_u0 > 0 (T >= 1 kK), finite itab_h"));
+        for (int f = 0; f < NF; ++f) {
+            if (!(pr->itab_tmin[f] > 0.)) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "itab_tmin must be > 0 (+inf: none)"));
+            if (std::isfinite(pr->itab_tmin[f]))
+                for (int k = 0; k < pr->itab_m * 8; ++k)
+                    if (!std::isfinite(pr->itab_coef[(size_t)f * pr->itab_m * 8 + k]))
+                        return bail(fail(LCF_ERR_INVALID_ARGUMENT, "non-finite interpolant coefficient"));
+        }
+    }
     if (have_htab) {
         if (pr->htab_off[0] != 0) return bail(fail(LCF_ERR_INVALID_ARGUMENT, "htab_off[0] must be 0"));
         for (int f = 0; f < NF; ++f)
@@ -1408,7 +1503,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<FiltDesc> hfd(NF);  // per filter: where its tables are and from which temperature each is valid
     for (int f = 0; f < NF; ++f)
         hfd[f] = FiltDesc{pfull[2 * f], pfull[2 * f + 1], pcomp[2 * f], pcomp[2 * f + 1], phot[2 * f], phot[2 * f + 1],
-                          0, 0,
+                          // the interpolant holds from max(its proved t_min, the table's first interval)
+                          (have_itab && std::isfinite(pr->itab_tmin[f]))
+                              ? (float)std::nextafter((float)std::max(std::log(pr->itab_tmin[f]), pr->itab_u0), INFINITY)
+                              : INFINITY,
+                          have_itab ? f * pr->itab_m * 8 : 0,
                           pcomp[2 * f + 1] > 0 ? 1. / ptmin[f] : 0.,  // t_min = 0 -> inf: always valid
                           phot[2 * f + 1] > 0 ? 1. / ptmin2[f] : 0.};
     std::vector<double> hexp(kExpTabSize);
@@ -1459,14 +1558,34 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.variant = 1;
     dp.use_ctab = have_ctab ? 1 : 0;
     e->have_ctab = have_ctab;
+    // third level: interpolants of ln S(ln T), staged in LDS behind the descriptors when they take <= 40 KiB
+    // (six to ten filters), else read from global memory (L2)
+    e->have_itab = have_itab;
+    dp.use_itab = have_itab ? 1 : 0;
+    dp.itab_m = have_itab ? pr->itab_m : 0;
+    dp.itab_u0 = have_itab ? pr->itab_u0 : 0.;
+    dp.itab_inv_h = have_itab ? 1. / pr->itab_h : 0.;
+    dp.itab_umax = have_itab ? pr->itab_u0 + pr->itab_h * pr->itab_m : 0.;
+    const size_t n_itab = have_itab ? (size_t)NF * pr->itab_m * 8 : 0;
+    // ... and only where a workgroup walks enough points to pay for staging them (a part of >= 1024 points; the
+    // population launches of 600-point transients read the 64 bytes a point needs from L2 instead: staging 24 KiB per
+    // workgroup cost them 20 %)
+    dp.n_itab_lds = (dp.tab_in_lds && n_itab * sizeof(double) <= 40 * 1024 && N >= 1024 * n_parts) ? (int)n_itab : 0;
+    dp.itab_uniform = have_itab ? 1 : 0;
+    for (int f = 0; have_itab && f < NF; ++f)
+        if (!(pr->itab_tmin[f] <= std::exp(pr->itab_u0) * (1. + 1e-12))) dp.itab_uniform = 0;
+    dp.stage_d2 = dp.n_lds_tab + 3 * NF + dp.n_itab_lds / 2;
     std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
     if (pr->model == LCF_MODEL_SHOCK_COOLING || pr->model == LCF_MODEL_SHOCK_COOLING3)
         dp.consts[11] = pr->consts[1] > 0. ? std::log(pr->consts[1] / 19.5) : 0.;  // hoisted out of the half-step
+    if (pr->model == LCF_MODEL_SHOCK_COOLING) {  // logarithms of the two amplitudes' constant factors (log-space state)
+        dp.consts[9] = std::log(pr->consts[6] * pr->consts[7] / kKB);
+        dp.consts[10] = std::log(kC3sq * pr->consts[5] * pr->consts[0]);
+    }
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
-    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) +
-                   (dp.tab_in_lds ? dp.n_lds_tab * sizeof(double2) + NF * sizeof(FiltDesc) : 0);
+    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)dp.stage_d2 * sizeof(double2) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
     int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
@@ -1479,6 +1598,14 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         double* dext;
         UP(hext, dext);
         dp.tab_ext = dext;
+    }
+    if (have_itab) {
+        std::vector<double> hit(pr->itab_coef, pr->itab_coef + (size_t)NF * pr->itab_m * 8);
+        for (double& v : hit)
+            if (!std::isfinite(v)) v = 0.;  // (filters without an interpolant: never read, u_min = +inf)
+        double* dit;
+        UP(hit, dit);
+        dp.itab = dit;
     }
     int* depoch;
     FiltDesc* dfd;
@@ -1527,10 +1654,12 @@ int64_t lcf_engine_npoints(const lcf_engine* e) { return e ? e->dp.n_points : 0;
 int64_t lcf_engine_samples_per_eval(const lcf_engine* e) { return e ? e->samples_per_eval : 0; }
 
 lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant) {
-    if (!e || variant < 0 || variant > 2) return fail(LCF_ERR_INVALID_ARGUMENT, "variant must be 0, 1 or 2");
-    if (variant == 2 && !e->have_ctab) return fail(LCF_ERR_INVALID_ARGUMENT, "no compressed tables were given");
+    if (!e || variant < 0 || variant > 3) return fail(LCF_ERR_INVALID_ARGUMENT, "variant must be 0, 1, 2 or 3");
+    if (variant >= 2 && !e->have_ctab) return fail(LCF_ERR_INVALID_ARGUMENT, "no compressed tables were given");
+    if (variant == 3 && !e->have_itab) return fail(LCF_ERR_INVALID_ARGUMENT, "no interpolants were given");
     e->dp.variant = variant == 0 ? 0 : 1;
-    e->dp.use_ctab = variant == 2 ? 1 : 0;
+    e->dp.use_ctab = variant >= 2 ? 1 : 0;
+    e->dp.use_itab = variant == 3 ? 1 : 0;
     return LCF_OK;
 }
 
@@ -1950,8 +2079,8 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
 
 // ---- one workgroup per proposal (k_solo): single-GPU runs whose parts fit one workgroup -----------------------------
 size_t solo_lds_bytes(const lcf_engine* e) {
-    return (kExpTabSize + 16) * sizeof(double) + (size_t)e->dp.n_lds_tab * sizeof(double2) +
-           (size_t)e->dp.n_filters * sizeof(FiltDesc) + (kSoloScratch + 4) * sizeof(double) +
+    return (kExpTabSize + 16) * sizeof(double) + (size_t)e->dp.stage_d2 * sizeof(double2) +
+           (kSoloScratch + 4) * sizeof(double) +
            (e->dp.use_therm ? (size_t)e->dp.n_epochs * sizeof(double2) : 0);
 }
 
@@ -1959,7 +2088,10 @@ bool solo_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_SOLO") != nullptr;
     const lcf_engine* e = s->e;
     // (the libm band sum, variant 0, exists to mirror the reference instruction for instruction: it keeps k_fused)
-    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
+    // (and light curves without shared epochs -- thermal state per point, inside the point loop -- keep k_fused too: there
+    // the serial head's registers on top of the point loop's do not fit 128 without spilling)
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.use_therm &&
+           e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
 }
 
 // One half-step of a single-GPU run: ONE launch, one workgroup per proposal, accept test and commit included.
@@ -1991,10 +2123,7 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
     do {                                                                                                              \
         if (e->dp.n_parts <= 2) LCF_SOLO4(ND, V, T, 2); else LCF_SOLO4(ND, V, T, 4);                                  \
     } while (0)
-#define LCF_SOLO(ND)                                                                                                  \
-    do {                                                                                                              \
-        if (e->dp.use_therm) LCF_SOLO3(ND, 1, true); else LCF_SOLO3(ND, 1, false);                                    \
-    } while (0)
+#define LCF_SOLO(ND) LCF_SOLO3(ND, 1, true)
     switch (ds.n_dim) {
         case 4: LCF_SOLO(4); break;
         case 5: LCF_SOLO(5); break;

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 5
+LCF_ABI_VERSION = 6
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -46,6 +46,8 @@ class LcfProblem(C.Structure):
                 ('t', _dp), ('y', _dp), ('dy', _dp), ('filt_idx', _ip), ('tab_off', _ip), ('tab_a', _dp),
                 ('tab_w', _dp), ('tab_ext', _dp), ('ctab_off', _ip), ('ctab_a', _dp), ('ctab_w', _dp), ('ctab_tmin', _dp),
                 ('htab_off', _ip), ('htab_a', _dp), ('htab_w', _dp), ('htab_tmin', _dp),
+                ('itab_coef', _dp), ('itab_tmin', _dp), ('itab_m', C.c_int32), ('reserved2', C.c_int32),
+                ('itab_u0', C.c_double), ('itab_h', C.c_double),
                 ('filt_kasen_par', _ip), ('filt_sifto_par', _ip), ('filt_dt_par', _ip),
                 ('n_knots', C.c_int32), ('reserved', C.c_int32), ('spline_knots', _dp), ('spline_coef', _dp),
                 ('priors', C.POINTER(LcfPrior))]
@@ -173,7 +175,7 @@ class Engine:
 
     def __init__(self, model_id, n_par, consts, t, y, dy, filt_idx, tab_off, tab_a, tab_w, use_sigma=False,
                  sigma_type=SIGMA_RELATIVE, priors=None, companion=None, device=0, ctab=None, tab_ext=None,
-                 htab=None):
+                 htab=None, itab=None):
         lib = load_library()
         self._lib = lib
         self._h = C.c_void_p()
@@ -211,6 +213,13 @@ class Engine:
                 raise ValueError('inconsistent hot-level tables')
             keep += hx
             pr.htab_off, pr.htab_a, pr.htab_w, pr.htab_tmin = _ptr(hx[0], _ip), _ptr(hx[1]), _ptr(hx[2]), _ptr(hx[3])
+        if itab is not None:  # (coef[n_filters, m, 8], tmin[n_filters], u0, h): interpolants of ln S(ln T)
+            ic, it = _f64(itab[0]), _f64(itab[1])
+            if ic.ndim != 3 or ic.shape[0] != pr.n_filters or ic.shape[2] != 8 or it.shape != (pr.n_filters,):
+                raise ValueError('inconsistent interpolant tables')
+            keep += [ic, it]
+            pr.itab_coef, pr.itab_tmin, pr.itab_m = _ptr(ic), _ptr(it), ic.shape[1]
+            pr.itab_u0, pr.itab_h = float(itab[2]), float(itab[3])
         if companion is not None:
             kp, sp, dtp, knots, coef = companion
             extra = [_i32(kp), _i32(sp), _i32(dtp), _f64(knots), _f64(coef)]

@@ -171,6 +171,77 @@ def prove_compressed_table(a, w, tol=COMPRESSION_TOL, orders=(12, 16, 24, 32), m
     return None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Third level: the band sum as a FUNCTION of temperature, tabulated once per (filter, redshift, cut-off)
+# ---------------------------------------------------------------------------------------------------------------
+#: the band sum of a filter depends on the walker through ONE number, the temperature: g(u) = ln S(e^u), u = ln T, is
+#: analytic in the strip |Im u| < pi/2, so piecewise polynomials of degree 7 on 64 equal intervals of u reproduce it to
+#: rounding between 2 and 256 kK.  A model whose temperature and radius are known in log space (power laws in time)
+#: then costs one table lookup, 7 fused multiply-adds and one exponential per data point instead of a sum over samples.
+INTERP_TMIN, INTERP_TMAX, INTERP_M, INTERP_DEGREE = 2.0, 256.0, 64, 7
+#: relative accuracy of exp(g) against the full sum: the evaluation floor of a log-space result (|ln L_nu| ~ 46 times
+#: a few roundings of 1.1e-16), a decade below it nothing is gained
+INTERP_TOL = 3e-13
+_interpolants = {}
+
+
+def interp_planck_table(a, w, t_lo=INTERP_TMIN, t_hi=INTERP_TMAX, m=INTERP_M, degree=INTERP_DEGREE, tol=INTERP_TOL):
+    """Piecewise-polynomial table of ``g(u) = ln sum_k W_k / (e^{a_k e^-u} - 1)`` on ``m`` equal intervals of
+    ``u = ln T`` between ``t_lo`` and ``t_hi``: per interval the polynomial of degree ``degree`` through its Chebyshev
+    points, stored as monomial coefficients in ``s in [-1, 1]`` (highest degree first, for Horner's rule).
+
+    Proved like the compressed tables: on 2048 temperatures across the range (the interpolant evaluated in float64
+    exactly as the device does, against the full float64 sum) the error of ``exp(g)`` must stay below ``tol`` from
+    some temperature ``t_min`` on -- hot bands pass everywhere, far-ultraviolet ones only above a few kK.  Returns
+    ``(coef[m, degree + 1], t_min, bound)`` or ``None`` if no part of the range can be proved (the engine then walks
+    the sample tables for that filter)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    key = (a.tobytes(), w.tobytes(), t_lo, t_hi, m, degree, tol)
+    if key in _interpolants:
+        return _interpolants[key]
+    def full(temps):  # float64 is enough here: its error (~1e-15 K^0.5 + x 1e-16) is two decades below tol
+        with np.errstate(over='ignore'):
+            return (w / np.expm1(np.multiply.outer(1. / temps, a))).sum(axis=1)
+    u0, u1 = np.log(t_lo), np.log(t_hi)
+    h = (u1 - u0) / m
+    k = np.arange(degree + 1)
+    xc = np.cos(np.pi * (2 * k + 1) / (2 * (degree + 1)))
+    centres = u0 + (np.arange(m) + 0.5) * h
+    nodes = centres[:, None] + 0.5 * h * xc[None, :]
+    with np.errstate(divide='ignore'):
+        gv = np.log(full(np.exp(nodes.ravel()))).reshape(m, degree + 1)
+    # interpolation through the same nodes in every interval: one (degree + 1)^2 system, highest power first
+    with np.errstate(invalid='ignore'):
+        coef = np.linalg.solve(np.vander(xc, degree + 1), gv.T).T
+    coef[~np.all(np.isfinite(gv), axis=1)] = np.nan
+    # the proof: the device's own evaluation (interval from u, Horner in float64, one exponential) against the full sum
+    temps = np.geomspace(t_lo, t_hi, 2048)
+    u = np.log(temps)
+    j = np.clip(((u - u0) * (1. / h)).astype(np.int64), 0, m - 1)
+    sloc = (u - (u0 + (j + 0.5) * h)) * (2. / h)
+    g = coef[j, 0]
+    for d in range(1, degree + 1):
+        g = g * sloc + coef[j, d]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        err = np.abs(np.expm1(g - np.log(full(temps))))
+    bad = np.nonzero(~(err <= tol))[0]
+    out = None
+    if len(bad) == 0:
+        out = (coef, float(t_lo), float(err.max()))
+    elif bad[-1] + 1 < len(temps) and temps[bad[-1]] < 0.25 * t_hi:
+        first = bad[-1] + 1   # valid from the next interval boundary above the last failing temperature
+        jb = min(m - 1, int(j[first]) + 1)
+        t_min = float(np.exp(u0 + jb * h))
+        good = temps >= t_min
+        if good.any() and np.all(err[good] <= tol):
+            out = (coef, t_min, float(err[good].max()))
+    if len(_interpolants) > 256:
+        _interpolants.clear()
+    _interpolants[key] = out
+    return out
+
+
 @total_ordering
 class Filter:
     """A broadband filter: identity, zero point and (lazily loaded) normalised transmission curve.
@@ -443,6 +514,17 @@ class PackedTables:
             setattr(self, names[2], np.asarray(oo, dtype=np.int32))
             setattr(self, names[3], np.asarray(tt, dtype=np.float64))
             setattr(self, names[4], np.asarray(bb, dtype=np.float64))
+
+        # third level: piecewise polynomials of ln S(ln T) per filter (None where it cannot be proved)
+        self.iu0, self.ih, self.im = float(np.log(INTERP_TMIN)), float(np.log(INTERP_TMAX / INTERP_TMIN) / INTERP_M), INTERP_M
+        self.icoef = np.zeros((len(self.filters), INTERP_M, INTERP_DEGREE + 1))
+        self.itmin = np.full(len(self.filters), np.inf)
+        self.ibound = np.full(len(self.filters), np.nan)
+        if compress and not reddening:
+            for i in range(len(self.filters)):
+                res = interp_planck_table(self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]])
+                if res is not None:
+                    self.icoef[i], self.itmin[i], self.ibound[i] = res
 
     def index(self, f):
         return self.filters.index(as_filter(f))

@@ -205,6 +205,7 @@ class Model:
                           companion=self._companion_tables(uniq), device=self.device if device is None else device,
                           ctab=None if self.reddened else (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
                           htab=None if self.reddened else (tabs.hoff, tabs.ha, tabs.hw, tabs.htmin),
+                          itab=None if self.reddened else (tabs.icoef, tabs.itmin, tabs.iu0, tabs.ih),
                           tab_ext=tabs.ext)
         eng.tables, eng.filt_idx = tabs, idx   # what was packed (measurement tools count the samples a fit executes)
         return eng
