@@ -51,7 +51,7 @@ struct PriorDev {
 // two Gauss-compressed companions, "cool" (valid for 1/T <= inv_tmin) and the shorter "hot" (1/T <= inv_tmin2).
 struct FiltDesc {
     int off, cnt, coff, ccnt, hoff, hcnt;
-    float u_min;   // ln of the temperature from which the filter's interpolant (below) is proved; +inf: none
+    float r_min;   // interval coordinate (ln T - itab_u0) / h from which the filter's interpolant is proved; +inf: none
     int ioff;      // its coefficients in the interpolant array, in doubles
     double inv_tmin, inv_tmin2;  // 0 = that level does not exist
 };
@@ -90,6 +90,8 @@ struct DevProblem {
     const int* pt_filt;  // filter index
     const int* pt_orig;  // index in the caller's order
     const int* pt_epoch; // index into epoch_t (distinct observation times)
+    const int* pt_fe;    // filter | epoch << 6 in one word (engines of at most 64 filters), else null
+    const double2* pt_yd;  // (y, 1/dy) per point -- (y, dy) when sigma is fitted -- for one 16-byte load
     const double* epoch_t; // [n_epochs]
     const double* exp2tab;   // 2^(j/256), j = 0..255
     const double2* tab;  // (a_k, W_k)
@@ -526,7 +528,9 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
 }
 
 // The same thermal state in LOG space, for the interpolated band sums (DevProblem::itab): a pair (x, p) with
-//   x > 0:            x = ln T_K (between the interpolants' ln 2 kK and ln 256 kK), p = ln R_bb^2
+//   x >= +0:          x = (ln T_K - itab_u0) / h, the temperature as a coordinate on the interpolants' intervals (its
+//                     integer part is the interval every filter's polynomial is taken from, 0 <= x < itab_m: 2 to
+//                     256 kK), p = ln R_bb^2 with |p| <= 600
 //   sign bit of x set: x = -1/T_K (-0.0 where the band integral vanishes), p = R_bb^2 (0, or NaN to propagate) -- the
 //                      linear-space state, for the sample-table band sum.
 // Power-law models never leave log space: ln T = c[6] + eT ln t and ln R_bb^2 = c[7] + eL ln t - E - 4 ln T come from
@@ -602,8 +606,10 @@ __device__ inline void thermal_state_log(const DevProblem& pb, const double* __r
         }
     }
     if (!(u == u) || !(u < 34.538776394910684)) return;  // T <= 0, NaN or >= 1e15 kK: zero band integral
-    if (u >= pb.itab_u0 && u <= pb.itab_umax) {
-        x = u;   // (> 0: the interpolants start at 2 kK)
+    if (lp < -600.) return;                                // R_bb^2 < e^-600: nothing (the reference: ~1e-260 of a datum)
+    const double r = (u - pb.itab_u0) * pb.itab_inv_h;
+    if (r >= 0. && r < (double)pb.itab_m && lp <= 600.) {
+        x = r;
         p = lp;
     } else if (u > -50.) {  // outside the interpolants' range: the sample tables, in linear space
         encode_linear(exp(-u), exp(lp), x, p);

@@ -104,11 +104,11 @@ __device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use
 // ln S_f(e^u) from the filter's interpolant: interval of u, then Horner's rule on 8 coefficients (four 16-byte reads).
 // `lds_at` >= 0: the interpolants are staged in LDS at that byte offset of the workgroup's dynamic LDS (the address is
 // formed from the LDS symbol itself, so that the reads are ds_read_b128 and not generic-pointer loads); < 0: global.
-__device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int lds_at, int ioff, double u) {
+// r = the temperature's interval coordinate (thermal_state_log): interval (int)r, position 2 frac(r) - 1 in [-1, 1).
+__device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int lds_at, int ioff, double r) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const double r = (u - pb.itab_u0) * pb.itab_inv_h;
-    const int j = min(max((int)r, 0), pb.itab_m - 1);
-    const double s = fma(r, 2., -(double)(2 * j + 1));   // in [-1, 1]
+    const int j = (int)r;
+    const double s = fma(__builtin_amdgcn_fract(r), 2., -1.);
     double2 q0, q1, q2, q3;
     if (lds_at >= 0) {
         const double2* q = reinterpret_cast<const double2*>(smem + lds_at) + (ioff + 8 * j) / 2;
@@ -129,7 +129,9 @@ __device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int 
 // Everything one lane does for its data point after the thermal state (1/T, R_bb^2): band sum(s) -> template term.
 // STAGED: the band tables (or their compressed levels) are in LDS; the on-the-fly reddening fall-back exists only in
 // the unstaged instantiations, so that it costs the staged kernels no registers.
-template <int VARIANT, bool STAGED>
+// ITAB: the instantiation may meet log-space states (engines with shared epochs only: with the thermal state inside the
+// point loop the interpolated path's registers do not fit next to it).
+template <int VARIANT, bool STAGED, bool ITAB>
 __device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
                                      const double* __restrict__ p, double t_in, int filt, const double2* tbase,
                                      const FiltDesc* fdesc, const ExpTab et, double invT, double pref, int itab_at) {
@@ -140,20 +142,20 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     // result never depends on how walkers are batched -- else the sample tables after one exponential each.
     bool by_table = false;
     int ioff = filt * pb.itab_m * 8;
-    if (VARIANT != 0 && pb.use_itab) {
+    if (ITAB && VARIANT != 0 && pb.use_itab) {
         const bool log_form = __double2hiint(invT) >= 0;   // (-0.0 and -1/T have the sign bit set)
         bool inside = log_form;
         if (!pb.itab_uniform || pb.model == kShockCooling4) {
-            const long long fmeta = __double_as_longlong(fd[1].y);   // {float u_min, int ioff} of the filter's interpolant
+            const long long fmeta = __double_as_longlong(fd[1].y);   // {float r_min, int ioff} of the filter's interpolant
             ioff = (int)(fmeta >> 32);
-            // (ShockCooling4 also needs the band sum at 0.74 T)
-            const double u_low = pb.model == kShockCooling4 ? invT - 0.3011050927839216 : invT;
-            inside = log_form && u_low >= (double)__int_as_float((int)fmeta);
+            // (ShockCooling4 also needs the band sum at 0.74 T: ln 0.74 / h intervals lower)
+            const double r_low = pb.model == kShockCooling4 ? invT - 0.3011050927839216 * pb.itab_inv_h : invT;
+            inside = log_form && r_low >= (double)__int_as_float((int)fmeta);
         }
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
             by_table = true;
         } else if (log_form) {  // a mixed wave: back to linear space
-            invT = exp(-invT);
+            invT = exp(-fma(invT, 1. / pb.itab_inv_h, pb.itab_u0));
             pref = exp(pref);
         } else {
             invT = -invT;
@@ -162,8 +164,9 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     if (by_table) {
         double L = interp_log_band_sum(pb, itab_at, ioff, invT);
         if (pb.model == kShockCooling4)  // min(blackbody, suppressed blackbody at 0.74 T), models.py:629-631
-            L = fmin(L, interp_log_band_sum(pb, itab_at, ioff, invT - 0.3011050927839216) + 1.2044203711356864);  // ln 0.74, -4 ln 0.74
-        yfit = exp_scaled<true>((L + pref) * kInvLn2N, et);
+            L = fmin(L, interp_log_band_sum(pb, itab_at, ioff, invT - 0.3011050927839216 * pb.itab_inv_h) + 1.2044203711356864);
+        // (|ln R_bb^2| <= 600 and |ln S| < 100: the exponent can be added as an integer)
+        yfit = exp_scaled<false>((L + pref) * kInvLn2N, et);
     } else if (!STAGED && invT > 0. && pb.redden_slow) {
         // ShockCooling3 through tables too long for LDS: the walker's reddening is applied sample by sample to the
         // full table in global memory (libm; a fall-back, not a fast path)
@@ -269,12 +272,28 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
             const int i = p0 + (k0 + u) * kBlock + tid;
             idx[u] = i < p1 ? i : -1;
             if (idx[u] < 0) continue;
-            filt[u] = pb.pt_filt[i];
-            tin[u] = pb.t[i];
-            if (THERM && MODE != 2) th[u] = th_base[pb.pt_epoch[i] - e_off];
+            // (filter and epoch share a word, and the time is fetched only by who uses it -- per-point thermal states,
+            // the SN Ia template, the (T, R) output: 20 instead of 32 bytes per point from L2)
+            if (THERM && MODE != 2) {
+                int ep;
+                if (pb.pt_fe) {
+                    const unsigned int fe = (unsigned int)pb.pt_fe[i];
+                    filt[u] = (int)(fe & 63u);
+                    ep = (int)(fe >> 6);
+                } else {
+                    filt[u] = pb.pt_filt[i];
+                    ep = pb.pt_epoch[i];
+                }
+                th[u] = th_base[ep - e_off];
+                tin[u] = pb.model >= kCompanion && pb.model <= kCompanion3 ? pb.t[i] : 0.;
+            } else {
+                filt[u] = pb.pt_filt[i];
+                tin[u] = pb.t[i];
+            }
             if (MODE == 0) {
-                yv[u] = pb.y[i];
-                idy[u] = pb.use_sigma ? pb.dy[i] : pb.inv_dy[i];
+                const double2 yd = pb.pt_yd[i];   // (y, 1/dy), or (y, dy) when sigma is fitted
+                yv[u] = yd.x;
+                idy[u] = yd.y;
             }
         }
 #pragma unroll
@@ -285,8 +304,6 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
             if (THERM && MODE != 2) {
                 invT = th[u].x;   // (the log-space pair of thermal_state_log when the engine interpolates)
                 pref = th[u].y;
-            } else if (MODE != 2 && VARIANT != 0 && pb.use_itab) {
-                thermal_state_log(pb, c, tin[u], invT, pref, et);
             } else {
                 thermal_state(pb, c, tin[u], Tk, invT, pref);
             }
@@ -297,7 +314,8 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 out1[j] = sqrt(pref);
                 continue;
             }
-            const double yfit = point_model<VARIANT, LDS_TAB>(pb, c, p, tin[u], filt[u], tbase, fdesc, et, invT, pref, itab_at);
+            const double yfit = point_model<VARIANT, LDS_TAB, THERM>(pb, c, p, tin[u], filt[u], tbase, fdesc, et, invT, pref,
+                                                                     itab_at);
             if (MODE == 0) {  // models.py:121-135
                 const double r = yv[u] - yfit;
                 if (pb.use_sigma) {
@@ -1505,7 +1523,8 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         hfd[f] = FiltDesc{pfull[2 * f], pfull[2 * f + 1], pcomp[2 * f], pcomp[2 * f + 1], phot[2 * f], phot[2 * f + 1],
                           // the interpolant holds from max(its proved t_min, the table's first interval)
                           (have_itab && std::isfinite(pr->itab_tmin[f]))
-                              ? (float)std::nextafter((float)std::max(std::log(pr->itab_tmin[f]), pr->itab_u0), INFINITY)
+                              ? std::nextafter((float)std::max((std::log(pr->itab_tmin[f]) - pr->itab_u0) / pr->itab_h, 0.),
+                                               INFINITY)
                               : INFINITY,
                           have_itab ? f * pr->itab_m * 8 : 0,
                           pcomp[2 * f + 1] > 0 ? 1. / ptmin[f] : 0.,  // t_min = 0 -> inf: always valid
@@ -1560,13 +1579,15 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     e->have_ctab = have_ctab;
     // third level: interpolants of ln S(ln T), staged in LDS behind the descriptors when they take <= 40 KiB
     // (six to ten filters), else read from global memory (L2)
-    e->have_itab = have_itab;
-    dp.use_itab = have_itab ? 1 : 0;
+    // (engines whose points share no epochs keep the thermal state inside the point loop, in linear space)
+    const bool have_itab_here = have_itab && all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
+    e->have_itab = have_itab_here;
+    dp.use_itab = have_itab_here ? 1 : 0;
     dp.itab_m = have_itab ? pr->itab_m : 0;
     dp.itab_u0 = have_itab ? pr->itab_u0 : 0.;
     dp.itab_inv_h = have_itab ? 1. / pr->itab_h : 0.;
     dp.itab_umax = have_itab ? pr->itab_u0 + pr->itab_h * pr->itab_m : 0.;
-    const size_t n_itab = have_itab ? (size_t)NF * pr->itab_m * 8 : 0;
+    const size_t n_itab = have_itab_here ? (size_t)NF * pr->itab_m * 8 : 0;
     // ... and only where a workgroup walks enough points to pay for staging them (a part of >= 1024 points; the
     // population launches of 600-point transients read the 64 bytes a point needs from L2 instead: staging 24 KiB per
     // workgroup cost them 20 %)
@@ -1611,6 +1632,20 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     FiltDesc* dfd;
     double *dexp, *depocht, *dinvdy;
     UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
+    {   // observation and the factor its residual is scaled with, side by side
+        std::vector<double2> hyd(N);
+        for (int i = 0; i < N; ++i) hyd[i] = make_double2(hy[i], pr->use_sigma ? hdy[i] : hinvdy[i]);
+        double2* dyd;
+        UP(hyd, dyd);
+        dp.pt_yd = dyd;
+    }
+    if (NF <= 64) {  // filter and epoch of a point in one word (epochs < 2^26 = the most points an engine takes)
+        std::vector<int> hfe(N);
+        for (int i = 0; i < N; ++i) hfe[i] = (int)((unsigned int)hfilt[i] | ((unsigned int)hepoch[i] << 6));
+        int* dfe;
+        UP(hfe, dfe);
+        dp.pt_fe = dfe;
+    }
     UP(hfd, dfd); UP(hinvdy, dinvdy); UP(pcomp, e->d_ctab_off); UP(ptmin, e->d_ctmin);
     dp.f_desc = dfd;
     dp.inv_dy = dinvdy;

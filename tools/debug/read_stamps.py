@@ -30,4 +30,6 @@ for n, v in zip(names, np.median(d, axis=0)):
 print('total', np.median(a[:, 10] - a[:, 0]), ' spread of entry stamps over the 64 workgroups', np.ptp(a[:, 0]))
 print('wave 1: staging done at', np.median(a[:, 11] - a[:, 0]), ' points done at', np.median(a[:, 12] - a[:, 0]),
       '(wave 0:', np.median(a[:, 8] - a[:, 0]), ')')
+print('points loop, wave 0: operands of the first iteration after', np.median(a[:, 13] - a[:, 7]), ' first iteration done after',
+      np.median(a[:, 14] - a[:, 7]), ' all iterations', np.median(a[:, 8] - a[:, 7]))
 print('device ms per step', s.last_run_ms / nst)
