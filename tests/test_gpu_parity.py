@@ -424,7 +424,7 @@ def test_table_levels_switch_without_a_seam():
     at two redshifts; plus the oracle on a coarse subset."""
     from lightcurve_fitting_amd.filters import PackedTables
     names = ['U', 'B', 'g', 'r', 'DLT40', 'UVW2', 'z', 'F2100W']
-    T = np.geomspace(0.25, 80., 3000)
+    T = np.geomspace(0.25, 600., 3000)
     R = np.full_like(T, 2.)
     for z in (0., 0.4):
         bb = M.Blackbody(redshift=z)
@@ -432,15 +432,67 @@ def test_table_levels_switch_without_a_seam():
         assert np.isfinite(tabs.htmin).sum() >= 4 and np.isfinite(tabs.ctmin).sum() >= 4
         eng, _ = bb._eval_engine(np.zeros(len(names)), names)
         out = {}
-        for v in (2, 0):
+        for v in (3, 2, 0):   # 3: interpolated ln S(ln T) between 2 and 256 kK (here through the generic log-space state)
             eng.set_variant(v)
             out[v] = eng.evaluate(np.column_stack([T, R]))        # (3000, nfilters)
         ok = out[0] > 0
-        assert np.array_equal(ok, out[2] > 0)
-        assert np.max(np.abs(out[2][ok] / out[0][ok] - 1.)) < 1e-11
+        for v in (3, 2):
+            assert np.array_equal(ok, out[v] > 0)
+            assert np.max(np.abs(out[v][ok] / out[0][ok] - 1.)) < 1e-11
         for j in (0, 2, 4):
             want = O.synthesize_blackbody(O.band(names[j]), T[::150], R[::150], z)
             assert relerr(out[2][::150, j], want) < TOL
+
+
+@pytest.mark.parametrize('model_name', ['ShockCooling2', 'ShockCooling4', 'CompanionShocking'])
+def test_interpolated_level_against_the_sample_tables(model_name):
+    """The third table level (ln S(ln T) per filter, log-space thermal states) against the libm sums over the full
+    tables and against the oracle: walkers whose temperatures run from far below 2 kK to far above 256 kK, so that whole
+    light curves, single waves and single points fall on either side of the interpolants' range; before the explosion;
+    out-of-domain parameters."""
+    rng = np.random.default_rng(11)
+    nw = 64
+    if model_name == 'CompanionShocking':
+        names8 = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'unfilt.']
+        epochs = 57001. + np.geomspace(0.02, 60., 160)
+        t, names = np.repeat(epochs, 8), list(np.tile(names8, len(epochs)))
+        lum0 = 2e20 * np.exp(-0.5 * ((t - 57018.) / 12.) ** 2)
+        m = M.CompanionShocking(lc_dict(t, names, lum0, 0.05 * lum0), redshift=0.003)
+        bands = [O.band(n) for n in names]
+        om = ('CompanionShocking', O.CompanionShockingOracle(bands, lum0, z=0.003, variant=1))
+        P = np.tile([57001., 0.5, 1.2, 57018., 1.05, 0.95, 0.9, 0.6], (nw, 1))
+        P[:, 1] = np.geomspace(1e-3, 1e3, nw)          # a13: T ~ a13^(1/4) -> 4 kK ... 140 kK at one day
+        P[:, 0] += rng.uniform(-0.5, 0.5, nw)
+        P[5, 2] = -1.                                   # M v^7 <= 0: no shock component
+    else:
+        epochs = np.geomspace(0.3, 60., 200)
+        t, names = np.repeat(epochs, 6), list(np.tile(list('UBVgri'), len(epochs)))
+        bands = [O.band(n) for n in names]
+        if model_name == 'ShockCooling2':
+            m, om = M.ShockCooling2(redshift=0.01), ('ShockCooling2', O.ShockCoolingOracle(0.01))
+            # (T_1 from 2 kK: at 60 d that is 0.3 kK; colder still, exp(a / T) overflows in the libm evaluation a few
+            # e-folds before the engine's gradual underflow reaches zero -- 1e-280 against 0, of data of 1e20)
+            P = np.column_stack([np.geomspace(2., 3000., nw), np.full(nw, 3.), np.full(nw, 20.), rng.uniform(-0.2, 0.5, nw)])
+            P[3, 0], P[4, 1] = -5., -1.                 # T_1 < 0 -> no light; L_1 < 0 -> NaN
+        else:
+            m, om = M.ShockCooling4(redshift=0.01), ('ShockCooling4', O.ShockCooling4Oracle(0.01))
+            P = np.column_stack([np.geomspace(0.02, 40., nw), np.full(nw, 0.5), np.full(nw, 3.), np.geomspace(50., 0.01, nw),
+                                 rng.uniform(-0.2, 0.5, nw)])
+    ytrue = 1e20 * (1 + rng.uniform(0., 1., len(t)))
+    lc = lc_dict(t, names, ytrue, 0.05 * ytrue)
+    eng = m.engine_for(lc)
+    out = {}
+    for v in (3, 0):
+        eng.set_variant(v)
+        out[v] = (eng.evaluate(P), eng.log_likelihood(P))
+    assert relerr(out[3][0], out[0][0]) < TOL and relerr(out[3][1], out[0][1]) < TOL   # (NaN patterns included)
+    some = [0, 3, 4, 5, 17, 31, 48, 63]
+    want = np.array([O.evaluate(om, t, bands, P[k]) for k in some])
+    assert relerr(out[3][0][some], want) < TOL
+    if model_name == 'ShockCooling2':   # the temperatures really straddle the range, and a wave straddles it too
+        T = np.array([O.ShockCoolingOracle(0.01).temperature_radius2(t, *P[k])[0] for k in (0, 20, 40, 63)])
+        assert np.nanmin(T) < 1. and np.nanmax(T) > 1000. and np.any((T[1] > 2.) & (T[1] < 256.))
+        assert np.any(T[2][:64] > 256.) and np.any(T[2][:64 * 3] < 256.)
 
 
 def test_long_tables_stage_only_their_compressed_levels():

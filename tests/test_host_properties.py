@@ -126,3 +126,30 @@ def test_every_compressed_level_of_every_table_is_proved(us, cutoff):
                 err = np.abs(comp - full) / np.abs(full)
                 assert np.all(err <= 1.25 * F.COMPRESSION_TOL), (_ALL_TABLES[i], z, temps[np.argmax(err)], err.max())
     assert n_levels > 150
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.floats(0., 1.), min_size=16, max_size=16), st.sampled_from([0., 0.5, 2.]))
+def test_every_interpolant_of_every_table_is_proved(us, z):
+    """The third level: ln S(ln T) of every bandpass table as piecewise polynomials.  Each carries the bound of its
+    pack-time proof (<= INTERP_TOL on 2048 temperatures from its t_min to 256 kK); evaluated the way the device does
+    (interval coordinate, Horner in float64, one exponential) at temperatures drawn between the proof temperatures it
+    stays within 1.5 x that tolerance of the full sum in extended precision."""
+    tabs = F.PackedTables(_ALL_TABLES, z=z)
+    assert np.sum(np.isfinite(tabs.itmin)) >= 58
+    for i in range(len(_ALL_TABLES)):
+        if not np.isfinite(tabs.itmin[i]):
+            assert np.isnan(tabs.ibound[i])
+            continue
+        assert F.INTERP_TMIN <= tabs.itmin[i] < 0.25 * F.INTERP_TMAX and tabs.ibound[i] <= F.INTERP_TOL
+        u = np.array(us[i % 4::4][:3] + [0., 1.])
+        temps = np.minimum(tabs.itmin[i] * (F.INTERP_TMAX / tabs.itmin[i]) ** u, F.INTERP_TMAX * (1 - 1e-12))
+        r = (np.log(temps) - tabs.iu0) * (1. / tabs.ih)
+        j = np.minimum(r.astype(np.int64), tabs.im - 1)
+        s = 2. * (r - j) - 1.
+        g = tabs.icoef[i, j, 0]
+        for d in range(1, tabs.icoef.shape[2]):
+            g = g * s + tabs.icoef[i, j, d]
+        full = F.band_sum_exact(tabs.a[tabs.off[i]:tabs.off[i + 1]], tabs.w[tabs.off[i]:tabs.off[i + 1]], temps)
+        err = np.abs(np.exp(g.astype(np.longdouble)) / full - 1.).astype(float)
+        assert np.all(err <= 1.5 * F.INTERP_TOL), (_ALL_TABLES[i], z, temps[np.argmax(err)], err.max())
