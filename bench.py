@@ -62,9 +62,9 @@ PEAK_FP32_TINSTR = 2 * PEAK_FP64_TINSTR                        # 157.3 TFLOP/s F
 PEAK_HBM_GBS = 8000.
 # Vector-ALU instructions per quad of samples in the shipped band-sum loop (58 FP64 + 23 other: exp via table and
 # degree-4 polynomial, four samples sharing one division), counted in the ISA of k_solo<5,1,true,2> by
-# tools/isa_count.py; the float32 SED loop (k_sed<1>): 80 per quad
+# tools/isa_count.py; the float32 SED loop (k_sed<1>, hardware exponential and reciprocal): 21 per quad
 VALU_PER_QUAD_F64 = 81
-VALU_PER_QUAD_F32 = 80
+VALU_PER_QUAD_F32 = 21
 # ... per data point on the interpolated path (variant 3: interval + Horner on 8 coefficients + one exponential +
 # residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (libm log + exp)
 VALU_PER_POINT_INTERP = 55

@@ -42,6 +42,22 @@ struct SedObs {
     const double* dy_med;   // [n_epochs] median(dy) of the epoch (sigma_type 'absolute')
 };
 
+// float32 band sum: per sample one multiply, v_exp_f32, one subtraction, v_rcp_f32 and one FMA (the hardware
+// exponential and reciprocal are good to 1 ulp; beyond x ~ 88.7 the exponential is +inf and the term 0, below -126 it is
+// flushed to 0 like the float32 result would be).  Tables are padded to quads with zero weights.
+template <class TabPtr>
+__device__ __forceinline__ float band_sum_f32(TabPtr tb, int cnt, float s2) {
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
+    for (int k = 0; k < cnt; k += 4) {
+        const float2 a0 = tb[k], a1 = tb[k + 1], a2 = tb[k + 2], a3 = tb[k + 3];
+        S0 = fmaf(a0.y, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a0.x * s2) - 1.f), S0);
+        S1 = fmaf(a1.y, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a1.x * s2) - 1.f), S1);
+        S2 = fmaf(a2.y, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a2.x * s2) - 1.f), S2);
+        S3 = fmaf(a3.y, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a3.x * s2) - 1.f), S3);
+    }
+    return (S0 + S1) + (S2 + S3);
+}
+
 template <int PREC>
 __global__ __launch_bounds__(kSedBlock) void k_sed(const SedDev sd, const SedObs ob, long long n_cand, int n_par,
                                                    int sigma_abs, int use_ctab, const double* __restrict__ cand,
@@ -111,17 +127,9 @@ __global__ __launch_bounds__(kSedBlock) void k_sed(const SedDev sd, const SedObs
             const int off = comp ? ds.z : ds.x, cnt = comp ? ds.w : ds.y;
             float S = 0.f;
             if (hot) {
-                const float2* tb = sd.tab_in_lds ? lt + off : sd.tab32 + off;
-                const float s2 = invT * 1.4426950408889634f;  // exp(x) = 2^(x log2 e): one v_exp_f32 per sample
-                float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
-                for (int k = 0; k < cnt; k += 4) {  // tables are padded to quads with zero weights
-                    const float2 a0 = tb[k], a1 = tb[k + 1], a2 = tb[k + 2], a3 = tb[k + 3];
-                    S0 = fmaf(a0.y, __frcp_rn(exp2f(a0.x * s2) - 1.f), S0);  // +inf beyond x ~ 88.7 -> term 0
-                    S1 = fmaf(a1.y, __frcp_rn(exp2f(a1.x * s2) - 1.f), S1);
-                    S2 = fmaf(a2.y, __frcp_rn(exp2f(a2.x * s2) - 1.f), S2);
-                    S3 = fmaf(a3.y, __frcp_rn(exp2f(a3.x * s2) - 1.f), S3);
-                }
-                S = (S0 + S1) + (S2 + S3);
+                const float s2 = invT * 1.4426950408889634f;  // exp(x) = 2^(x log2 e)
+                // (two branches so that the staged tables are read with LDS instructions, not through a generic pointer)
+                S = sd.tab_in_lds ? band_sum_f32(lt + off, cnt, s2) : band_sum_f32(sd.tab32 + off, cnt, s2);
             }
             const float yfit = R * R * S;
             const float dy = (float)ob.dy[o];
