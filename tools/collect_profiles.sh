@@ -8,7 +8,8 @@ TAG=${1:-r02}
 COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT $R/profiles
+FINAL=$OUT/final   # everything that is to be committed under profiles/ (gpurun merges gpurun_out/ only)
+mkdir -p $OUT $FINAL
 cd /tmp && export TMPDIR=/tmp
 declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
 declare -A PSTEPS=( [mcmc]=5 [companion]=2 [population]=3 [sed]=1 )
@@ -17,7 +18,7 @@ declare -A PTAG=( [mcmc]=k_solo_mcmc [companion]=k_solo_companion [population]=p
 for W in mcmc companion population sed; do
   echo "== $W: kernel trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 $R/bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/trace_$W.log
-  cp $OUT/trace_$W/*/*_kernel_stats.csv $R/profiles/${TAG}_kernel_stats_$W.csv 2>/dev/null
+  cp $OUT/trace_$W/*/*_kernel_stats.csv $FINAL/${TAG}_kernel_stats_$W.csv 2>/dev/null
   i=0
   for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
@@ -25,8 +26,8 @@ for W in mcmc companion population sed; do
     echo "== $W: pmc pass $i"
     rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${W}_$i -- python3 $R/tools/prof_kernel.py $W ${PSTEPS[$W]} > $OUT/pmc_${W}_$i.log 2>&1
   done
-  python3 - "$OUT" "$W" "${KERNEL[$W]}" "$R/profiles/${TAG}_pmc_${PTAG[$W]}.json" "$COMMIT" "$R" <<'PY'
-import csv, glob, collections, json, sys
+  python3 - "$OUT" "$W" "${KERNEL[$W]}" "$FINAL/${TAG}_pmc_${PTAG[$W]}.json" "$COMMIT" "$R" <<'PY'
+import csv, glob, collections, json, re, sys
 out, w, kern, dst, commit, root = sys.argv[1:7]
 sys.path.insert(0, root)
 import bench
@@ -35,7 +36,8 @@ for p in sorted(glob.glob(out + f'/pmc_{w}_*/*/*_counter_collection.csv')):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
         if kern in r['Kernel_Name']:
-            name = r['Kernel_Name'].split('(')[0]
+            m = re.search(r'(k_\w+(<[^>]*>)?)', r['Kernel_Name'])
+            name = m.group(1) if m else r['Kernel_Name'][:60]
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         res[k] = {'mean_per_launch': sum(v) / len(v), 'launches': len(v)}
@@ -46,8 +48,12 @@ PY
 done
 echo "== unprofiled bench lines"
 cd $R
+mkdir -p profiles && cp $FINAL/${TAG}_pmc_*.json profiles/
 for W in mcmc companion population sed; do
-  python3 bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 > profiles/${TAG}_bench_$W.json 2> /dev/null
+  python3 bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 > $FINAL/${TAG}_bench_$W.json 2> /dev/null
 done
-python3 bench.py --steps 1000 --warmup 5 --variant 1 --no-cpu-baseline > profiles/${TAG}_bench_mcmc_full_tables.json 2> /dev/null
-ls -la profiles/ | tail -20
+python3 bench.py --steps 1000 --warmup 5 --variant 2 --no-cpu-baseline > $FINAL/${TAG}_bench_mcmc_compressed_tables.json 2> /dev/null
+python3 bench.py --steps 1000 --warmup 5 --variant 1 --no-cpu-baseline > $FINAL/${TAG}_bench_mcmc_full_tables.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $FINAL/${TAG}_bench_mcmc_20_steps.json 2> /dev/null
+rm -rf $OUT/trace_* $OUT/pmc_*_[0-9]
+ls -la $FINAL
