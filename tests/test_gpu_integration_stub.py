@@ -54,7 +54,7 @@ def test_reference_side_binding_runs_as_written():
     f = S.make_vectorized_log_posterior(lc, RefModel(), priors, library=LIB_PATH)
     P = pb['truth'] * (1 + 0.05 * np.random.default_rng(2).standard_normal((16, 5)))
     P[3, 0] = 11.                    # outside its prior: -inf, likelihood skipped (fitting.py:125)
-    want = np.array([O.log_posterior(pb['model'], pb['t'], pb['bands'], pb['y'], pb['dy'], pb['priors'], p) for p in P])
+    want = np.array([O.log_posterior(('ShockCooling', pb['orc']), pb['t'], pb['bands'], pb['y'], pb['dy'], pb['priors'], p) for p in P])
     got = f(P)
     assert got[3] == -np.inf and relerr(got, want) < 1e-11
     assert relerr(f(P[0]), want[:1]) < 1e-11
