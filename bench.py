@@ -434,8 +434,11 @@ def run_mcmc(args):
         name = {'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
                         '+ likelihood + accept test)',
                 'fused': 'k_fused<5,1,true>', 'phases': 'k_step + k_points'}[used]
+        # the committed counters are those of the default configuration (k_solo, interpolated level); any other
+        # kernel or table level has no PMC pass of its own and reports null
+        pmc_tag = 'k_solo_mcmc' if (used, args.variant) == ('solo', 3) else f'k_{used}_v{args.variant}_mcmc'
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, ALG_INSTR,
-                              ALG_BYTES, 'k_solo_mcmc', waves_per_launch=(per_rank // 2) * 8,
+                              ALG_BYTES, pmc_tag, waves_per_launch=(per_rank // 2) * 8,
                               interp=(n_interp, N_EPOCHS) if n_interp else None)
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
