@@ -212,16 +212,9 @@ int32_t lcf_sampler_one_launch(const lcf_sampler* s);
  * same chain bit for bit; the choice exists for tests and measurements.
  *   AUTO:   one workgroup per proposal that also accepts / rejects (k_solo) where a proposal's parts fit one
  *           workgroup, else one workgroup per (proposal, part) (k_fused), else proposal + likelihood launches
- *   SOLO:   the same        FUSED:  never k_solo        PHASES: always proposal + likelihood launches
- *   RUN:    an experiment kept selectable (lcf_sampler_run only; never chosen by AUTO): the workgroups of k_solo stay
- *           resident for a whole block of steps -- ONE launch -- and hand rows to each other through tagged words in
- *           uncached memory (k_run).  The launch needs every workgroup resident at once: if it does not get the whole
- *           device (another process runs a launch of the same kind) it gives up after 0.5 s, the run returns
- *           LCF_ERR_STATE and the sampler's state is undefined until the next lcf_sampler_set_state.
- * Returns in *used (optional) what lcf_sampler_run would use now: 3 = k_run, 2 = k_solo, 1 = k_fused, 0 = separate
- * launches. */
-enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2, LCF_HALF_STEP_SOLO = 3,
-       LCF_HALF_STEP_RUN = 4 };
+ *   FUSED:  never k_solo        PHASES: always proposal + likelihood launches
+ * Returns in *used (optional) what a run would use now: 2 = k_solo, 1 = k_fused, 0 = separate launches. */
+enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2 };
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new

@@ -451,7 +451,7 @@ struct DrawRec {
     double z;          // stretch factor
     double zl;         // (n_dim - 1) ln z
     double lnu;        // ln u
-    int wage, page;    // half-steps since the walker / the partner last moved (1..3; 0 without slot bookkeeping)
+    double pad;
 };
 
 struct DevSampler {
@@ -476,12 +476,6 @@ struct DevSampler {
     // own copy.  mbox = this rank's, peer_mbox[r] = rank r's as mapped here (own included).
     unsigned long long* mbox;
     unsigned long long* peer_mbox[kMaxPeers];
-    // Row board of the one-launch-per-block run (k_run): [kRing versions][n_walkers][n_dim + 1] 16-byte entries in
-    // uncached memory, the walker's position and log-posterior after each of its moves, tagged with the half-step;
-    // progress[block] = half-steps of the run the workgroup has finished, progress[n_half] = abort word.
-    unsigned long long* board;
-    unsigned int* progress;
-    int n_run_blocks;
 };
 
 // One float64 as two 8-byte granules {32 data bits, 32-bit generation tag}: an 8-byte store is the largest that
@@ -590,8 +584,7 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     if (i >= n_act) {
         d.wid = d.pid = d.wprev = d.pprev = -1;
         d.z = 1.;
-        d.zl = d.lnu = 0.;
-        d.wage = d.page = 0;
+        d.zl = d.lnu = d.pad = 0.;
         draws[idx] = d;
         return;
     }
@@ -613,21 +606,7 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     d.z = z;
     d.zl = (double)(sm.n_dim - 1) * log(z);
     d.lnu = log(u01(s2[0], s2[1]));
-    // Every walker moves once per step, in one of its two half-steps: a walker that was not active in the half-step in
-    // front (half-step G - 1) moved in the one before it, or -- the walker of a step's SECOND half-step only -- three
-    // half-steps ago (first half of the previous step).  The one-launch-per-block run waits for exactly that version
-    // of each row.  (Before the first step of a run every age points in front of the run: its start state.)
-    d.wage = d.page = 0;
-    if (slot_of) {
-        if (half == 0) {
-            d.wage = before[d.wid] >= 0 ? 1 : 2;
-            d.page = before[d.pid] >= 0 ? 1 : 2;
-        } else {
-            const int* two_back = slot_of + (size_t)(row * 2) * sm.n_walkers;  // second half of the previous step
-            d.wage = two_back[d.wid] >= 0 ? 2 : 3;
-            d.page = 1;
-        }
-    }
+    d.pad = 0.;
     draws[idx] = d;
 }
 
@@ -648,7 +627,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
     const int pp = (int)((g - 1) & 1), cp = (int)(g & 1);
     constexpr int kD = ND > 0 ? ND : kMaxDim;     // array extent
     const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
-    DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0, 0};
+    DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
     if (have_next) dr = draws[i];
     const bool active = have_next && dr.wid >= 0;  // (an odd ensemble leaves the last slot of its second half-step empty)
     // --- roles: which accept test (if any) this lane evaluates ---
@@ -1119,315 +1098,6 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     LCF_STAMP(0, 10);
 }
 
-// ---- single-GPU fit, one launch per BLOCK of steps (k_run): half-steps without kernel boundaries -------------------
-// k_solo spends a quarter of a 1024-walker half-step between kernels (end-of-kernel write-back, dispatch, ramp) and on
-// loads that start from nothing (draw record, then rows).  Here the workgroups of k_solo stay resident for all
-// half-steps of a block of draw records and hand rows to each other directly: a commit posts the walker's position and
-// log-posterior on the row board (uncached memory; per number two 8-byte {32 data bits, 32-bit tag} granules, tag =
-// half-step + 1, version ring of kRing), and the serial head of a later half-step polls the board for exactly the
-// version of its walker and of its partner that the draw record names (DrawRec::wage / page) -- the only dependency
-// the stretch move has.  No grid barrier.  Two things keep that safe:
-//  * every workgroup of the grid must be resident (the host sizes the grid to the device: lcf_sampler_run only), and
-//    every wait is bounded (0.5 s of the wall clock), after which the launch aborts through a flag in the same
-//    uncached memory and the run ends with an error instead of hanging;
-//  * nobody starts half-step G before every workgroup has finished G - 2 (plain progress words, checked by an otherwise
-//    idle wave in the shadow of the serial head): half-steps G - 1 and G are the only ones in flight, they read
-//    versions >= G - 3 and write G and G + 1, so a ring of 8 versions is never overrun.
-// Same arithmetic as k_solo in the same order: bitwise the same chain.
-constexpr int kRing = 8;
-
-__device__ inline unsigned long long* board_entry(const DevSampler& sm, unsigned int tag, int wid, int col) {
-    return sm.board + 2 * ((((size_t)(tag & (kRing - 1)) * sm.n_walkers) + wid) * (sm.n_dim + 1) + col);
-}
-__device__ inline void board_post(const DevSampler& sm, unsigned int tag, int wid, int col, double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
-    unsigned long long* p = board_entry(sm, tag, wid, col);
-    __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ inline bool run_aborted(const DevSampler& sm) {
-    return __hip_atomic_load(sm.progress + sm.n_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-}
-// (what: 1 = a row of the board, a = tag, b = walker, c = column; 2 = the progress words, a = half-step of the run)
-__device__ inline void run_abort(const DevSampler& sm, unsigned int what, unsigned int a, unsigned int b, unsigned int c) {
-    unsigned int* flag = sm.progress + sm.n_half;
-    if (atomicCAS_system(flag, 0u, 1u) == 0u) {   // the first one to give up says what it was waiting for
-        __hip_atomic_store(flag + 1, what, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(flag + 2, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(flag + 3, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(flag + 4, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    atomicOr(sm.err, 2);
-}
-// The number with tag `tag`, once it is there (bounded wait; NaN after an abort).
-__device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col) {
-    const unsigned long long* p = board_entry(sm, tag, wid, col);
-    const unsigned long long t0 = wall_clock64();
-    for (int spin = 0;; ++spin) {
-        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned int)(a >> 32) == tag && (unsigned int)(b >> 32) == tag)
-            return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
-        if ((spin & 15) == 15) {
-            if (run_aborted(sm)) return qnan();
-            if (wall_clock64() - t0 > 50000000ull) {
-                run_abort(sm, 1u, tag, (unsigned int)wid, (unsigned int)col);
-                return qnan();
-            }
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// Start of a run: every walker's row as version `tag` (= the run's first half-step: "the state in front of it").
-__global__ void k_board_init(const DevSampler sm, unsigned int tag) {
-    const int cols = sm.n_dim + 1;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    // progress words count the half-steps of THIS run; word n_half is the abort flag (+ 4 words: what was missing)
-    if (idx <= sm.n_half + 4) __hip_atomic_store(sm.progress + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (idx >= (long long)sm.n_walkers * cols) return;
-    const int wid = (int)(idx / cols), col = (int)(idx % cols);
-    board_post(sm, tag, wid, col, col < sm.n_dim ? sm.X[(size_t)wid * sm.n_dim + col] : sm.LP[wid]);
-}
-
-// Everything the launch is given, as ONE by-value argument: the loop below re-reads what it needs from the kernel-argument
-// segment in every half-step (scalar loads, as a one-half-step kernel does at its start) instead of carrying some 400
-// scalar registers of hoisted arguments -- and what the compiler derives from them -- through the point loop.
-struct RunArgs {
-    DevProblem pb;
-    DevSampler sm;
-    long long rel0, g0, g_run0;   // first half-step: relative to the run / in the sampler's numbering; the run's first
-    int n_hs;                     // half-steps in this launch
-    const DrawRec* draws;
-};
-typedef const RunArgs __attribute__((address_space(4)))* RunArgsPtr;
-
-// One proposal (slot i of the launch's half-step h) in its workgroup: k_solo with rows from and to the board.  Returns
-// false when the launch is aborted.
-template <int ND, int VARIANT, bool THERM, int NPARTS>
-__device__ __forceinline__ bool run_proposal(RunArgsPtr ka, int h, int i) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int kThreads = kBlock * NPARTS;
-    constexpr int kD = ND > 0 ? ND : kMaxDim;
-    const int tid = threadIdx.x;
-    const DevProblem& pb = *(const DevProblem*)&ka->pb;
-    const DevSampler& sm = *(const DevSampler*)&ka->sm;
-    const DrawRec* __restrict__ draws = ka->draws;
-    const long long g0 = ka->g0, g_run0 = ka->g_run0;
-    double* exptab = reinterpret_cast<double*>(smem);
-    double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
-    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
-    const int itab_at = pb.n_itab_lds > 0
-                            ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
-    double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);  // coefficients, then log-prior
-    double* sq = sc + kNCoef + 2;                                           // the proposal
-    double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp
-    int* sctl = reinterpret_cast<int*>(sc + kSoloScratch + 2);              // [0]: 1 = the launch is aborted (sx[kMaxDim] is the lp)
-    double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
-    const int nd = ND > 0 ? ND : sm.n_dim;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool reddened = pb.model == kShockCooling3;
-    const unsigned int tag_floor = (unsigned int)g_run0;   // rows nobody has moved in this run carry the run's start tag
-    const long long G = g0 + h;                 // this half-step in the sampler's numbering (tags)
-    const long long row = (ka->rel0 + h) / 2;   // chain row
-    LCF_STAMP(0, 0);
-    const DrawRec dr = draws[(size_t)h * sm.n_half + i];     // wave-uniform
-    const bool active = dr.wid >= 0;  // (an odd ensemble's smaller colour leaves its last slot empty)
-    if (wave == 0 && active) {
-        // ---- serial head: rows from the board -> proposal -> logarithms -> coefficients, log-prior
-        const long long tw = G - dr.wage + 1, tp = G - dr.page + 1;
-        const unsigned int tag_w = tw < g_run0 ? tag_floor : (unsigned int)tw;
-        const unsigned int tag_p = tp < g_run0 ? tag_floor : (unsigned int)tp;
-        // lanes 0 .. nd-1: the partner's position; lanes 16 .. 16+nd: the walker's position and log-posterior
-        const bool own = lane >= 16;
-        const int col = own ? lane - 16 : lane;
-        PriorDev my_prior{0, 0, 0., 0., 0., 1.};
-        if (lane < pb.n_dim && pb.has_priors) my_prior = pb.priors[lane];
-        double got = 0.;
-        if (own ? col <= nd : col < nd) got = board_take(sm, own ? tag_w : tag_p, own ? dr.wid : dr.pid, col);
-        LCF_STAMP(0, 1);
-        double x[kD], q[kMaxDim], lq[kMaxDim];
-#pragma unroll
-        for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
-        const double lp_i = __shfl(got, 16 + nd, 64);
-        double arg = 1.;
-#pragma unroll
-        for (int d = 0; d < kD; ++d) {
-            const double xd = __shfl(got, 16 + d, 64), cj = __shfl(got, d, 64);
-            x[d] = d < nd ? xd : 0.;
-            q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
-            if (lane == d && d < pb.n_par) arg = q[d];
-        }
-        LCF_STAMP(0, 2);
-        const double lg = flog(arg);
-#pragma unroll
-        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
-        LCF_STAMP(0, 3);
-        double c[kNCoef];
-        walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
-        LCF_STAMP(0, 4);
-        double lpr = 0.;
-        if (pb.has_priors) {
-            double qv = 0.;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (lane == d) qv = q[d];
-            const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
-            sc[kNCoef] = lpr;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (d < nd) {
-                    sq[d] = q[d];
-                    sx[d] = x[d];
-                }
-            sx[kMaxDim] = lp_i;
-        }
-        LCF_STAMP(0, 5);
-    } else if (wave == 1) {
-        // ---- in the shadow of the head: has everybody finished half-step G - 2?  has anybody given up?
-        // (and touch the record this workgroup needs next, so that it waits in this XCD's L2)
-        bool abort = false;
-        if (i == (int)blockIdx.x) {
-            if (lane == 63 && h + 1 < ka->n_hs) {
-                const volatile int* nxt = reinterpret_cast<const volatile int*>(draws + (size_t)(h + 1) * sm.n_half + i);
-                (void)nxt[0];
-                (void)nxt[sizeof(DrawRec) / sizeof(int) - 1];
-            }
-            const long long need = G - 1;   // progress word of a workgroup that has finished G - 2
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                bool ok = true;
-                if (need > g0) {   // (earlier half-steps ended with an earlier launch)
-                    const unsigned int want = (unsigned int)(need - g_run0);
-                    for (int b0 = 0; b0 < sm.n_run_blocks; b0 += 8 * 64) {
-                        unsigned int seen[8];   // eight loads in flight, not one after the other
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int b = b0 + 64 * k + lane;
-                            seen[k] = b < sm.n_run_blocks ? __hip_atomic_load(sm.progress + b, __ATOMIC_RELAXED,
-                                                                                __HIP_MEMORY_SCOPE_SYSTEM) : want;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) ok = ok & (seen[k] >= want);
-                    }
-                }
-                abort = run_aborted(sm);
-                if (__all(ok) || abort) break;
-                if (wall_clock64() - t0 > 50000000ull) {
-                    run_abort(sm, 2u, (unsigned int)(G - g_run0), 0u, 0u);
-                    abort = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (lane == 0) sctl[0] = abort ? 1 : 0;
-        }
-        LCF_STAMP(1, 11);
-    }
-    __syncthreads();
-    LCF_STAMP(0, 6);
-    if (sctl[0] != 0) return false;   // (uniform: everybody reads the same word)
-    const double lpr = active ? sc[kNCoef] : -INFINITY;
-    double term = 0.;
-    const bool excluded = lpr == -INFINITY;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
-    if (!excluded) {
-        double cs[kNCoef];
-#pragma unroll
-        for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
-        if (reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, cs[6], tid, kThreads);
-        const int part = tid / kBlock, ltid = tid % kBlock;
-        if (THERM) {
-            const int e0 = part_entry(pb.part_ep0, part), e1 = part_entry(pb.part_ep0, part + 1);
-#pragma unroll 1
-            for (int e = e0 + ltid; e < e1; e += kBlock) {
-                double T, invT, pref;
-                if (pb.use_itab)
-                    thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
-                else
-                    thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
-                lth[e] = make_double2(invT, pref);
-            }
-        }
-        if (THERM || reddened) __syncthreads();
-        LCF_STAMP(0, 7);
-        if (part < pb.n_parts)
-            term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
-                                                           nullptr, nullptr, ltid, itab_at);
-        LCF_STAMP(0, 8);
-        LCF_STAMP(1, 12);
-        const double ws = wave_sum(term);
-        if (lane == 0) red[wave] = ws;
-    }
-    __syncthreads();
-    LCF_STAMP(0, 9);
-    if (wave == 0 && active) {
-        // ---- accept / reject, commit and post (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move)
-        double nlp = -INFINITY;
-        if (!excluded) {
-            double sum = pb.use_sigma ? 0. : pb.log_norm_const;   // fixed order: parts, each (w0 + w1) + (w2 + w3)
-            for (int k = 0; k < pb.n_parts; ++k) sum += (red[4 * k] + red[4 * k + 1]) + (red[4 * k + 2] + red[4 * k + 3]);
-            nlp = lpr - 0.5 * sum;
-        }
-        const double lp_i = sx[kMaxDim];
-        const bool ok = (dr.zl + nlp - lp_i) > dr.lnu;   // emcee: (ndim - 1) ln z + lp_new - lp_old > ln u
-        if (lane <= nd) {
-            const double v = lane < nd ? (ok ? sq[lane] : sx[lane]) : (ok ? nlp : lp_i);
-            board_post(sm, (unsigned int)(G + 1), dr.wid, lane, v);
-            // (device-scope stores: half-steps apart, workgroups on different XCDs write the same walker's row, and
-            // two private L2s must not each keep their own dirty copy of it until the launch ends)
-            if (ok)
-                __hip_atomic_store(lane < nd ? sm.X + (size_t)dr.wid * nd + lane : sm.LP + dr.wid, v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            if (sm.store_chain) {
-                if (lane < nd)
-                    sm.chain[((size_t)row * sm.n_walkers + dr.wid) * nd + lane] = v;
-                else
-                    sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = v;
-            }
-        }
-        if (lane == 0) {
-            if (nlp != nlp) atomicOr(sm.err, 1);
-            if (ok) atomicAdd(reinterpret_cast<unsigned long long*>(&sm.nacc[dr.wid]), 1ull);
-        }
-    }
-    LCF_STAMP(0, 10);
-    return true;
-}
-
-template <int ND, int VARIANT, bool THERM, int NPARTS>
-__global__ __launch_bounds__(kBlock * NPARTS, LCF_WAVES)
-void k_run(const RunArgs args_by_value) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int kThreads = kBlock * NPARTS;
-    const RunArgsPtr ka = (RunArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    const int n_hs = ka->n_hs, n_half = ka->sm.n_half;
-    {
-        const DevProblem& pb = *(const DevProblem*)&ka->pb;
-        if (pb.model != kShockCooling3 && threadIdx.x >= 128) {
-            double* exptab = reinterpret_cast<double*>(smem);
-            double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
-            stage_tables<VARIANT, true>(pb, exptab, ltab, 0., threadIdx.x - 128, kThreads - 128);
-        }
-    }
-#pragma unroll 1
-    for (int h = 0; h < n_hs; ++h) {
-#pragma unroll 1
-        for (int i = blockIdx.x; i < n_half; i += gridDim.x)
-            if (!run_proposal<ND, VARIANT, THERM, NPARTS>(ka, h, i)) return;
-        if (threadIdx.x == 0)   // (half-steps of the run this workgroup has finished)
-            __hip_atomic_store(ka->sm.progress + blockIdx.x, (unsigned int)(ka->g0 + h + 1 - ka->g_run0), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // State of the sampler as 8-byte words into (mapped, pinned) host memory: [error flag | X | LP | n_accepted].
 __global__ void k_snapshot(const DevSampler sm, unsigned long long* __restrict__ out) {
     const long long nx = (long long)sm.n_walkers * sm.n_dim, nw = sm.n_walkers;
@@ -1498,7 +1168,6 @@ namespace {
 
 struct lcf_engine {
     int device = 0;
-    int n_cu = 0;               // compute units of the device
     DevProblem dp{};
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
@@ -1693,7 +1362,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 
     auto* e = new lcf_engine();
     e->device = device;
-    if (hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) e->n_cu = 0;
     lcf_status st = LCF_OK;
     auto bail = [&](lcf_status s) {
         delete e;
@@ -2181,7 +1849,6 @@ struct lcf_sampler {
     bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
     int half_step_kernel = LCF_HALF_STEP_AUTO;
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
-    void* board_mem = nullptr;               // row board + progress words of the one-launch-per-block run (uncached)
     std::vector<void*> opened;               // peers' mailboxes mapped through IPC
     int peer_ranks = 0, peer_rank = 0;
     // Snapshot of (error flag, positions, log-posteriors, acceptance counts) in pinned host memory, copied behind the
@@ -2203,7 +1870,6 @@ struct lcf_sampler {
         free_blocks();
         for (void* p : opened) hipIpcCloseMemHandle(p);
         if (mailbox) hipFree(mailbox);
-        if (board_mem) hipFree(board_mem);
         if (snap) hipHostFree(snap);
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
@@ -2459,9 +2125,7 @@ bool solo_eligible(const lcf_sampler* s) {
     // (the libm band sum, variant 0, exists to mirror the reference instruction for instruction: it keeps k_fused)
     // (and light curves without shared epochs -- thermal state per point, inside the point loop -- keep k_fused too: there
     // the serial head's registers on top of the point loop's do not fit 128 without spilling)
-    const bool wanted = s->half_step_kernel == LCF_HALF_STEP_AUTO || s->half_step_kernel == LCF_HALF_STEP_SOLO ||
-                        s->half_step_kernel == LCF_HALF_STEP_RUN;
-    return !disabled && wanted && e->dp.variant != 0 && e->dp.use_therm &&
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.use_therm &&
            e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
 }
 
@@ -2509,84 +2173,6 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
 #undef LCF_SOLO4
     LCF_HIP(hipGetLastError());
     return leave_half_step(s, st);
-}
-
-// ---- one launch per block of steps (k_run): the workgroups of k_solo, resident for a whole block of draw records --------
-bool run_eligible(const lcf_sampler* s) {
-    // (only on request: at configs[1] the hand-over through the board costs what the kernel boundary costs, see
-    // DESIGN.md section 5, and the launch needs the whole device)
-    return s->half_step_kernel == LCF_HALF_STEP_RUN && solo_eligible(s);
-}
-
-// Board and progress words: allocated with the first such run.
-lcf_status run_board_alloc(lcf_sampler* s) {
-    if (s->board_mem) return LCF_OK;
-    DevSampler& ds = s->ds;
-    const size_t board = (size_t)kRing * ds.n_walkers * (ds.n_dim + 1) * 2 * sizeof(unsigned long long);
-    const size_t bytes = board + ((size_t)ds.n_half + 5) * sizeof(unsigned int);
-    // uncached (fine-grained) device memory: stores and polls of workgroups on different XCDs meet in memory
-    LCF_HIP(hipExtMallocWithFlags(&s->board_mem, bytes, hipDeviceMallocUncached));
-    LCF_HIP(hipMemset(s->board_mem, 0, bytes));
-    ds.board = reinterpret_cast<unsigned long long*>(s->board_mem);
-    ds.progress = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(s->board_mem) + board);
-    ds.n_run_blocks = 0;
-    return LCF_OK;
-}
-
-// The half-steps [rel0, rel0 + n_hs) of the current run -- all inside one block of draw records -- as ONE launch.
-// *blocks_out: workgroups the launch may use (every one of them must be resident at the same time).
-lcf_status launch_run(lcf_sampler* s, long long rel0, int n_hs, hipStream_t st) {
-    lcf_engine* e = s->e;
-    DevSampler& ds = s->ds;
-    const DrawRec* draws = s->rows(rel0);
-    const size_t lds = solo_lds_bytes(e);
-    const long long g0 = s->g_run0 + rel0;
-#define LCF_RUN4(ND, V, T, NP)                                                                                        \
-    do {                                                                                                              \
-        static int per_cu = -1; /* per instantiation: resident workgroups per CU at this LDS size */                  \
-        static size_t per_cu_lds = 0;                                                                                 \
-        if (per_cu < 0 || per_cu_lds != lds) {                                                                        \
-            if (lds > 64 * 1024)                                                                                      \
-                LCF_HIP(hipFuncSetAttribute((const void*)k_run<ND, V, T, NP>,                                         \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));             \
-            LCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_run<ND, V, T, NP>, kBlock * NP, lds));    \
-            per_cu_lds = lds;                                                                                         \
-        }                                                                                                             \
-        const long long room = (long long)per_cu * e->n_cu;                                                           \
-        if (room < 1) return fail(LCF_ERR_UNSUPPORTED, "k_run does not fit the device");                                   \
-        ds.n_run_blocks = (int)std::min<long long>(ds.n_half, room);                                                  \
-        const RunArgs args{e->dp, ds, rel0, g0, (long long)s->g_run0, n_hs, draws};                                   \
-        hipLaunchKernelGGL((k_run<ND, V, T, NP>), dim3((unsigned)ds.n_run_blocks), dim3(kBlock * NP), lds, st, args); \
-    } while (0)
-#define LCF_RUN(ND)                                                                                                   \
-    do {                                                                                                              \
-        if (e->dp.n_parts <= 2) LCF_RUN4(ND, 1, true, 2); else LCF_RUN4(ND, 1, true, 4);                              \
-    } while (0)
-    switch (ds.n_dim) {  // (an experiment kept selectable: the benchmark's dimension and the generic instantiation)
-        case 5: LCF_RUN(5); break;
-        default: LCF_RUN(0); break;
-    }
-#undef LCF_RUN
-#undef LCF_RUN4
-    LCF_HIP(hipGetLastError());
-    return LCF_OK;
-}
-
-// A whole run that way: the board takes the run's start state, then one launch per block of draw records.
-lcf_status enqueue_run_blocks(lcf_sampler* s, int64_t n_steps, hipStream_t st) {
-    if (lcf_status r = run_board_alloc(s)) return r;
-    DevSampler& ds = s->ds;
-    const long long cells = std::max<long long>((long long)ds.n_walkers * (ds.n_dim + 1), ds.n_half + 5);
-    hipLaunchKernelGGL(k_board_init, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ds, (unsigned int)s->g_run0);
-    LCF_HIP(hipGetLastError());
-    for (int64_t k = 0; k < n_steps;) {
-        if (lcf_status r = enter_half_step(s, 2 * k, st)) return r;
-        const int64_t b = s->blk_current, len = s->block_start(b) + s->block_len(b) - k;
-        if (lcf_status r = launch_run(s, 2 * k, (int)(2 * len), st)) return r;
-        if (lcf_status r = leave_half_step(s, st)) return r;
-        k += len;
-    }
-    return LCF_OK;
 }
 
 // Log-posteriors of the shard's proposals from their partial sums (sharded runs: the all-gather sends these).
@@ -2871,10 +2457,10 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
 }
 void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used) {
-    if (!s || choice < LCF_HALF_STEP_AUTO || choice > LCF_HALF_STEP_RUN)
+    if (!s || choice < LCF_HALF_STEP_AUTO || choice > LCF_HALF_STEP_PHASES)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad half-step kernel choice");
     s->half_step_kernel = choice;
-    if (used) *used = run_eligible(s) ? 3 : solo_eligible(s) ? 2 : fused_eligible(s) ? 1 : 0;
+    if (used) *used = solo_eligible(s) ? 2 : fused_eligible(s) ? 1 : 0;
     return LCF_OK;
 }
 
@@ -2903,21 +2489,7 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (lcf_status st = settle(s)) return st;
     int err = 0;
     std::memcpy(&err, s->snap, sizeof(int));
-    if (err & 2) {
-        unsigned int w[5] = {0, 0, 0, 0, 0};
-        if (s->board_mem) hipMemcpy(w, s->ds.progress + s->ds.n_half, sizeof w, hipMemcpyDeviceToHost);
-        if (w[0]) {
-            char msg[256];
-            if (w[1] == 1)
-                std::snprintf(msg, sizeof msg, "k_run: version %u of walker %u (column %u) was not posted within 0.5 s: the "
-                              "launch did not get the whole device (LCF_NO_PERSIST=1 avoids that launch)", w[2], w[3], w[4]);
-            else
-                std::snprintf(msg, sizeof msg, "k_run: half-step %u of the run waited 0.5 s for the other workgroups: the "
-                              "launch did not get the whole device (LCF_NO_PERSIST=1 avoids that launch)", w[2]);
-            return fail(LCF_ERR_STATE, msg);
-        }
-        return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
-    }
+    if (err & 2) return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;
 }
@@ -3154,31 +2726,21 @@ lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_s
     return lcf_sampler_wait(s);
 }
 
-}  // extern "C"
-
-namespace {
-// Enqueue a whole single-GPU run on the engine's stream.  `whole_device`: the caller will wait for this run before it
-// starts another one on the device, so the run may use the launch that keeps every workgroup resident (k_run).
-lcf_status enqueue_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode, const int32_t* perm,
-                       int32_t store_chain, bool whole_device) {
+// Enqueue a whole run on the engine's stream and return: several samplers (one engine each = one transient of a
+// population) then execute concurrently on the device.  lcf_sampler_wait() completes it.
+lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 const int32_t* perm, int32_t store_chain) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    const bool blocks = whole_device && run_eligible(s);
-    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, blocks || !solo_eligible(s)))
-        return st;
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, !solo_eligible(s))) return st;
     hipStream_t st = s->e->stream;
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
-    // per half-step: ONE launch (k_solo, k_fused) when everything a workgroup needs fits in LDS -- or one launch per
-    // block of steps (k_run) --, else [commit previous + draw + thermal states] -> [per-point likelihood]; one
-    // trailing commit
+    // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else
+    // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
     const bool fused = fused_eligible(s);
-    if (blocks || solo_eligible(s)) {  // one workgroup per proposal, nothing pending between launches
-        if (blocks) {
-            if (lcf_status r = enqueue_run_blocks(s, n_steps, st)) return r;
-        } else {
-            for (int64_t k = 0; k < 2 * n_steps; ++k)
-                if (lcf_status r = launch_solo(s, k, st)) return r;
-        }
+    if (solo_eligible(s)) {  // one workgroup per proposal, nothing pending between launches
+        for (int64_t k = 0; k < 2 * n_steps; ++k)
+            if (lcf_status r = launch_solo(s, k, st)) return r;
         s->g_next += 2 * n_steps;
         LCF_HIP(hipEventRecord(s->ev1, st));
         if (lcf_status r = enqueue_snapshot(s)) return r;
@@ -3197,16 +2759,6 @@ lcf_status enqueue_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int3
     if (lcf_status r = enqueue_snapshot(s)) return r;
     return speculate_continuation(s, st);
 }
-}  // namespace
-
-extern "C" {
-
-// Enqueue a whole run on the engine's stream and return: several samplers (one engine each = one transient of a
-// population) then execute concurrently on the device.  lcf_sampler_wait() completes it.
-lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
-                                 const int32_t* perm, int32_t store_chain) {
-    return enqueue_run(s, first_step, n_steps, split_mode, perm, store_chain, false);
-}
 
 lcf_status lcf_sampler_wait(lcf_sampler* s) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
@@ -3218,7 +2770,7 @@ lcf_status lcf_sampler_wait(lcf_sampler* s) {
 
 lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                            const int32_t* perm, int32_t store_chain) {
-    if (lcf_status st = enqueue_run(s, first_step, n_steps, split_mode, perm, store_chain, true)) return st;
+    if (lcf_status st = lcf_sampler_run_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     return lcf_sampler_wait(s);
 }
 

@@ -425,15 +425,13 @@ class NativeSampler:
         return bool(self._lib.lcf_sampler_one_launch(self._h))
 
     def set_half_step_kernel(self, choice='auto'):
-        """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'solo' | 'fused' | 'phases' | 'run';
-        same chain bit for bit).  Returns what ``run`` uses now: 'solo' (one launch per half-step, one workgroup per
-        proposal, accept test included), 'fused' (one workgroup per proposal and part), 'phases' (proposal +
-        likelihood launches) or 'run' (on request only: one launch per block of steps, resident workgroups that hand
-        rows to each other)."""
+        """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'fused' | 'phases'; same chain bit
+        for bit).  Returns what a run uses now: 'solo' (one workgroup per proposal, accept test included), 'fused'
+        (one workgroup per proposal and part) or 'phases' (proposal + likelihood launches)."""
         used = C.c_int32()
-        _check(self._lib.lcf_sampler_set_half_step_kernel(self._h, {'auto': 0, 'fused': 1, 'phases': 2, 'solo': 3, 'run': 4}[choice],
+        _check(self._lib.lcf_sampler_set_half_step_kernel(self._h, {'auto': 0, 'fused': 1, 'phases': 2}[choice],
                                                           C.byref(used)))
-        return {3: 'run', 2: 'solo', 1: 'fused', 0: 'phases'}[used.value]
+        return {2: 'solo', 1: 'fused', 0: 'phases'}[used.value]
 
     def half_step_rows(self, step, half, lo, hi, stream=0):
         _check(self._lib.lcf_sampler_half_step_rows(self._h, int(step), int(half), int(lo), int(hi),

@@ -306,10 +306,3 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
         shared_epochs = re.search(r'k_(solo|fused)ILi\dELi1ELb1E', k) or re.search(r'k_pointsILi1ELi0ELb1ELb1E', k)
         assert int(f['SGPRs Spill']) <= (128 if shared_epochs else 192), (k, f)
         assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
-    # the selectable one-launch-per-block experiment (k_run): a loop around the whole half-step; what the compiler keeps
-    # live across it may cost a few spilled registers outside the point loop, never the occupancy
-    runs = [k for k in blocks if re.search(r'k_runILi[05]ELi1ELb1ELi[24]E', k)]
-    assert len(runs) == 4, sorted(blocks)[:5]
-    for k in runs:
-        f = blocks[k]
-        assert int(f['Occupancy']) >= 4, (k, f)

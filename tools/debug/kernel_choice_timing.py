@@ -16,7 +16,7 @@ model, lc, priors = bench.build_problem(0)
 eng = model.engine_for(lc, priors=priors)
 x0 = bench.initial_walkers(nw)
 chains = {}
-for kernel in ('run', 'solo', 'fused', 'run', 'solo'):
+for kernel in ('auto', 'fused', 'phases', 'auto', 'fused'):
     s = NativeSampler(eng, nw, 11)
     used = s.set_half_step_kernel(kernel)
     s.set_state(x0)
