@@ -599,11 +599,15 @@ def run_population(args):
         eng = pop[pop.indices[0]].engine
         eng._variant = args.variant
         quads, n_interp = quads_per_evaluation(eng, first_truth)
-        pair_ms = pop.last_run_ms / (2 * args.steps)    # one k_step_multi + one k_points_multi per half-step
+        pair_ms = pop.last_run_ms / (2 * args.steps)    # the launch(es) of one half-step of all transients
+        used = pop[pop.indices[0]]._native.last_run_kernel()
+        name = {'population': 'k_pop<5,1,4> (ONE launch per half-step for all 32 transients of this GPU: a workgroup per '
+                              'four proposals, serial heads side by side, accept test included)',
+                'population-phases': 'k_step_multi + k_points_multi (the two launches of a half-step of all 32 '
+                                     'transients of this GPU; the likelihood launch dominates)'}[used]
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
-        roof = roofline_block('k_step_multi + k_points_multi (the two launches of a half-step of all 32 transients of this '
-                              'GPU; the likelihood launch dominates)', pair_ms, 32 * nw // 2, quads, VALU_PER_QUAD_F64,
-                              PEAK_FP64_TINSTR, alg_instr, ALG_BYTES, 'population',
+        roof = roofline_block(name, pair_ms, 32 * nw // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr, ALG_BYTES,
+                              'population' if (used, args.variant) == ('population', 3) else f'{used}_v{args.variant}',
                               interp=(n_interp, 100) if n_interp else None)
         out = {'metric': 'walker-steps/sec (population of independent ensembles)',
                'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,

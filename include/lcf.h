@@ -197,7 +197,9 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
                                  const int32_t* perm, int32_t store_chain);
 lcf_status lcf_sampler_wait(lcf_sampler* s);
 /* Population mode: run n samplers (independent transients with the same walker count, on one device) in lock step:
- * one proposal launch and one likelihood launch per half-step cover all of them.  split_mode: identity or random. */
+ * ONE launch per half-step covers all of them where every transient has shared epochs, tables staged in LDS and
+ * proposal-independent tables (k_pop), else one proposal launch and one likelihood launch.  split_mode: identity or
+ * random.  LCF_NO_POP=1 in the environment forces the two launches (tests). */
 lcf_status lcf_population_run(lcf_sampler** samplers, int32_t n, int64_t first_step, int64_t n_steps,
                               int32_t split_mode, int32_t store_chain, double* elapsed_ms);
 /* Chain of the last run: chain[n_steps][n_walkers][n_dim], log_prob[n_steps][n_walkers] (either may be NULL). */
@@ -216,6 +218,13 @@ int32_t lcf_sampler_one_launch(const lcf_sampler* s);
  * Returns in *used (optional) what a run would use now: 2 = k_solo, 1 = k_fused, 0 = separate launches. */
 enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2 };
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used);
+
+/* What the half-steps of the sampler's last run were executed by (-1: no run yet): separate proposal / likelihood
+ * launches, k_fused, k_solo; for lcf_population_run one launch per half-step for all transients (k_pop: a workgroup per
+ * four proposals, accept test included) or the two launches k_step_multi + k_points_multi. */
+enum { LCF_KERNEL_PHASES = 0, LCF_KERNEL_FUSED = 1, LCF_KERNEL_SOLO = 2, LCF_KERNEL_POPULATION = 3,
+       LCF_KERNEL_POPULATION_PHASES = 4 };
+int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
  * log-probabilities (RCCL) between phase 2 and phase 3.  All enqueue on `stream` without host sync.

@@ -931,6 +931,68 @@ __device__ unsigned long long g_stamps[64 * 16];
 #define LCF_STAMP(W, k) do {} while (0)
 #endif
 
+// The serial head of one proposal, executed by ONE wave (lane = 0..63): rows of the walker and of its partner ->
+// proposal -> logarithms (one parameter per lane) -> coefficients, log-prior; lane 0 leaves them in LDS: sc[0 .. kNCoef)
+// the coefficients, sc[kNCoef] the log-prior, sq the proposal, sx the walker's position and sx[kMaxDim] its
+// log-posterior.
+template <int ND>
+__device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
+                                              double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx) {
+    constexpr int kD = ND > 0 ? ND : kMaxDim;
+    const int nd = ND > 0 ? ND : sm.n_dim;
+    PriorDev my_prior{0, 0, 0., 0., 0., 1.};
+    if (lane < pb.n_dim && pb.has_priors) my_prior = pb.priors[lane];
+    const double* xs = sm.X + (size_t)dr.wid * nd;
+    const double* cs_ = sm.X + (size_t)dr.pid * nd;
+    double x[kD], q[kMaxDim], lq[kMaxDim];
+#pragma unroll
+    for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
+    const double lp_i = sm.LP[dr.wid];
+    double arg = 1.;
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+        x[d] = d < nd ? xs[d] : 0.;
+        const double cj = d < nd ? cs_[d] : 0.;
+        q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
+        if (lane == d && d < pb.n_par) arg = q[d];
+    }
+#ifdef LCF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    LCF_STAMP(0, 2);
+    const double lg = flog(arg);
+#pragma unroll
+    for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
+    LCF_STAMP(0, 3);
+    double c[kNCoef];
+    walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
+    LCF_STAMP(0, 4);
+    double lpr = 0.;
+    if (pb.has_priors) {
+        double qv = 0.;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (lane == d) qv = q[d];
+        const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
+        sc[kNCoef] = lpr;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) {
+                sq[d] = q[d];
+                sx[d] = x[d];
+            }
+        sx[kMaxDim] = lp_i;
+    }
+    LCF_STAMP(0, 5);
+}
+
 // ---- single-GPU fit, one workgroup per PROPOSAL: a half-step that owns its accept test ------------------------------
 // k_fused gives every (proposal, part) its own workgroup, so no workgroup knows the proposal's likelihood: the accept
 // test is re-derived by whoever needs the walker in the next launch, from per-slot records (proposal, draw, partial
@@ -969,59 +1031,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
     LCF_STAMP(0, 1);
     if (tid < 64) {
-        // ---- serial head, one wave: proposal -> logarithms (one parameter per lane) -> coefficients, log-prior
-        const int lane = tid;
-        PriorDev my_prior{0, 0, 0., 0., 0., 1.};
-        if (lane < pb.n_dim && pb.has_priors) my_prior = pb.priors[lane];
-        const double* xs = sm.X + (size_t)dr.wid * nd;
-        const double* cs_ = sm.X + (size_t)dr.pid * nd;
-        double x[kD], q[kMaxDim], lq[kMaxDim];
-#pragma unroll
-        for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
-        const double lp_i = sm.LP[dr.wid];
-        double arg = 1.;
-#pragma unroll
-        for (int d = 0; d < kD; ++d) {
-            x[d] = d < nd ? xs[d] : 0.;
-            const double cj = d < nd ? cs_[d] : 0.;
-            q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
-            if (lane == d && d < pb.n_par) arg = q[d];
-        }
-#ifdef LCF_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        LCF_STAMP(0, 2);
-        const double lg = flog(arg);
-#pragma unroll
-        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
-        LCF_STAMP(0, 3);
-        double c[kNCoef];
-        walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
-        LCF_STAMP(0, 4);
-        double lpr = 0.;
-        if (pb.has_priors) {
-            double qv = 0.;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (lane == d) qv = q[d];
-            const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
-            sc[kNCoef] = lpr;
-#pragma unroll
-            for (int d = 0; d < kD; ++d)
-                if (d < nd) {
-                    sq[d] = q[d];
-                    sx[d] = x[d];
-                }
-            sx[kMaxDim] = lp_i;
-        }
-        LCF_STAMP(0, 5);
+        proposal_head<ND>(pb, sm, dr, tid, sc, sq, sx);
     } else {
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
@@ -1147,6 +1157,132 @@ __global__ __launch_bounds__(kBlock) void k_points_multi(const MultiItem* __rest
     if ((int)blockIdx.x >= nh * it.pb.n_parts) return;
     points_body<VARIANT, 0, LDS_TAB, THERM>(it.pb, blockIdx.x, 0, nh, it.sm.Q[parity], it.coef, it.lprior, it.therm,
                                             it.sm.part2[parity], nullptr);
+}
+
+// ---- population mode, ONE launch per half-step (k_pop): a workgroup takes FOUR proposals of one transient -----------
+// The two launches above spend most of a half-step in k_step_multi's latency chain and in global round trips (proposal,
+// coefficients, thermal states and partial sums all travel through memory).  Here one workgroup of four waves owns four
+// consecutive proposal slots of a transient: it stages the transient's tables once, every wave runs the serial head of
+// ONE of the proposals (four latency chains side by side instead of one after the other), all threads then compute the
+// thermal states of the four proposals together and walk the points proposal by proposal -- thread t takes the points
+// t, t + 256, ... of a part exactly as a k_points workgroup does, same reduction tree, so a transient's chain is bitwise
+// the one the two-launch path produces -- and lane 0 of wave w accepts or rejects and commits proposal w.  Nothing
+// between launches but the committed state: no slot records, no coefficients, no thermal states in memory.  The
+// transient's DevProblem is read through a constant-address-space pointer: scalar loads, as kernel arguments are.
+constexpr int kPopScratch = kSoloScratch + 6;   // doubles per proposal: k_solo's + (ln z term, ln u, walker id), padded
+constexpr int kPopMaxParts = 4;
+
+#ifndef LCF_POP_WAVES
+#define LCF_POP_WAVES LCF_WAVES
+#endif
+// GROUP = proposals (= waves) per workgroup: 4, or 8 with two proposals' points walked side by side (threads
+// [0, 256) and [256, 512), each half exactly as a k_points workgroup).
+template <int ND, int VARIANT, int GROUP>
+__global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiItem* __restrict__ items, long long rel) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef const MultiItem __attribute__((address_space(4)))* ItemPtr;
+    const ItemPtr itp = (ItemPtr)(items + blockIdx.y);
+    const MultiItem& it = *(const MultiItem*)itp;
+    const DevProblem& pb = it.pb;
+    const DevSampler& sm = it.sm;
+    constexpr int kThreads = 64 * GROUP, kSide = GROUP / 4;
+    const int nh = sm.n_half, slot0 = blockIdx.x * GROUP;
+    if (slot0 >= nh) return;
+    double* exptab = reinterpret_cast<double*>(smem);
+    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
+    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
+    const int itab_at = pb.n_itab_lds > 0
+                            ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+    double* scratch = reinterpret_cast<double*>(ltab + pb.stage_d2);       // [GROUP][kPopScratch]
+    double* red = scratch + GROUP * kPopScratch;                             // [GROUP][4 * kPopMaxParts] wave sums
+    double2* lth = reinterpret_cast<double2*>(red + GROUP * 4 * kPopMaxParts);  // [GROUP][n_epochs]
+    constexpr int kD = ND > 0 ? ND : kMaxDim;
+    const int nd = ND > 0 ? ND : sm.n_dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_ep = pb.n_epochs;
+    stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid, kThreads);
+    {
+        // ---- the serial heads, one per wave, side by side
+        double* sc = scratch + wave * kPopScratch;
+        double* sq = sc + kNCoef + 2;
+        double* sx = sq + kMaxDim + (kMaxDim & 1);
+        const int slot = slot0 + wave;
+        DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0.};
+        if (slot < nh) dr = item_rows(it, rel)[slot];     // wave-uniform
+        const bool active = dr.wid >= 0;  // (an odd ensemble's smaller colour leaves its last slot empty)
+        if (active) proposal_head<ND>(pb, sm, dr, lane, sc, sq, sx);
+        if (lane == 0) {
+            if (!active) sc[kNCoef] = -INFINITY;
+            sx[kMaxDim + 1] = dr.zl;
+            sx[kMaxDim + 2] = dr.lnu;
+            reinterpret_cast<int*>(sx + kMaxDim + 3)[0] = dr.wid;
+        }
+    }
+    __syncthreads();
+    // ---- thermal states of all proposals, one (proposal, epoch) pair per thread and round
+    for (int idx = tid; idx < GROUP * n_ep; idx += kThreads) {
+        const int w = idx / n_ep, e = idx - w * n_ep;
+        const double* sc = scratch + w * kPopScratch;
+        if (sc[kNCoef] == -INFINITY) continue;   // the prior excludes the proposal (or the slot is empty)
+        double T, invT, pref;
+        if (pb.use_itab)
+            thermal_state_log(pb, sc, pb.epoch_t[e], invT, pref, ExpTab{exptab});
+        else
+            thermal_state(pb, sc, pb.epoch_t[e], T, invT, pref);
+        lth[(size_t)w * n_ep + e] = make_double2(invT, pref);
+    }
+    __syncthreads();
+    // ---- the points, proposal by proposal (kSide of them side by side)
+    const int side = wave / 4, ltid = tid & (kBlock - 1);
+#pragma unroll 1
+    for (int w = side; w < GROUP; w += kSide) {
+        const double* sc = scratch + w * kPopScratch;
+        if (sc[kNCoef] == -INFINITY) continue;   // (uniform within each side: its threads read the same word)
+        double cs[kNCoef];
+#pragma unroll
+        for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
+#pragma unroll 1
+        for (int part = 0; part < pb.n_parts; ++part) {
+            const double term = points_loop<VARIANT, 0, true, true, 1>(pb, part, 0, sc + kNCoef + 2, cs, lth + (size_t)w * n_ep, 0,
+                                                                       ltab, fdesc, ExpTab{exptab}, nullptr, nullptr, ltid, itab_at);
+            const double ws = wave_sum(term);
+            if (lane == 0) red[(w * kPopMaxParts + part) * 4 + (wave & 3)] = ws;
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    // ---- accept / reject and commit (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move), one lane per proposal
+    const double* sc = scratch + wave * kPopScratch;
+    const double* sq = sc + kNCoef + 2;
+    const double* sx = sq + kMaxDim + (kMaxDim & 1);
+    const int wid = reinterpret_cast<const int*>(sx + kMaxDim + 3)[0];
+    if (wid < 0) return;
+    const double lpr = sc[kNCoef];
+    double nlp = -INFINITY;
+    if (lpr != -INFINITY) {
+        double sum = pb.use_sigma ? 0. : pb.log_norm_const;   // fixed order: parts, each (w0 + w1) + (w2 + w3)
+        const double* r = red + wave * kPopMaxParts * 4;
+        for (int k = 0; k < pb.n_parts; ++k) sum += (r[4 * k] + r[4 * k + 1]) + (r[4 * k + 2] + r[4 * k + 3]);
+        nlp = lpr - 0.5 * sum;
+    }
+    const double lp_i = sx[kMaxDim];
+    const bool ok = (sx[kMaxDim + 1] + nlp - lp_i) > sx[kMaxDim + 2];   // emcee: (ndim - 1) ln z + lp_new - lp_old > ln u
+    if (nlp != nlp) atomicOr(sm.err, 1);
+    if (ok) {
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) sm.X[(size_t)wid * nd + d] = sq[d];
+        sm.LP[wid] = nlp;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sm.nacc[wid]), 1ull);  // (no return value: nothing waits)
+    }
+    if (sm.store_chain) {
+        const long long row = rel / 2;
+        double* crow = sm.chain + ((size_t)row * sm.n_walkers + wid) * nd;
+#pragma unroll
+        for (int d = 0; d < kD; ++d)
+            if (d < nd) crow[d] = ok ? sq[d] : sx[d];
+        sm.chain_lp[(size_t)row * sm.n_walkers + wid] = ok ? nlp : lp_i;
+    }
 }
 
 }  // namespace
@@ -1848,6 +1984,7 @@ struct lcf_sampler {
     bool pending = false;     // the last proposed half-step is not committed yet
     bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
     int half_step_kernel = LCF_HALF_STEP_AUTO;
+    int last_kernel = -1;     // what the last run's half-steps were (lcf_sampler_last_run_kernel)
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
     std::vector<void*> opened;               // peers' mailboxes mapped through IPC
     int peer_ranks = 0, peer_rank = 0;
@@ -2464,6 +2601,8 @@ lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int3
     return LCF_OK;
 }
 
+int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s) { return s ? s->last_kernel : -1; }
+
 int32_t lcf_sampler_one_launch(const lcf_sampler* s) { return s && (solo_eligible(s) || fused_eligible(s)) ? 1 : 0; }
 
 lcf_status lcf_sampler_half_step_rows(lcf_sampler* s, int64_t step, int32_t half, int32_t lo, int32_t hi,
@@ -2738,6 +2877,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else
     // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
     const bool fused = fused_eligible(s);
+    s->last_kernel = solo_eligible(s) ? LCF_KERNEL_SOLO : fused ? LCF_KERNEL_FUSED : LCF_KERNEL_PHASES;
     if (solo_eligible(s)) {  // one workgroup per proposal, nothing pending between launches
         for (int64_t k = 0; k < 2 * n_steps; ++k)
             if (lcf_status r = launch_solo(s, k, st)) return r;
@@ -2827,18 +2967,61 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
         max_parts = std::max(max_parts, items[t].pb.n_parts);
     }
+    // One launch per half-step (k_pop: a workgroup per four proposals, accept test included) where every transient has
+    // shared epochs, staged tables, the fast band sum, at most kPopMaxParts merged parts and tables that do not depend
+    // on the proposal (ShockCooling3's reddened tables do); else the two launches below.
+    const DevProblem& p0 = s0->e->dp;
+    bool one_launch = std::getenv("LCF_NO_POP") == nullptr && thermal && p0.variant != 0 && p0.tab_in_lds &&
+                      max_parts <= kPopMaxParts;
+    size_t pop_lds = 0;
+    // Proposals per workgroup: 4.  (Measured at 32 x 512 walkers x 600 points: 49.0 us per half-step; staging the
+    // interpolants in LDS as well costs occupancy, 61.7 us; workgroups of 8 proposals that can afford it, 50.4 us;
+    // five waves per SIMD at the price of 8 spilled registers, 47.0 us.)
+    constexpr int pop_group = 4;
+    for (int t = 0; t < n; ++t) one_launch = one_launch && ss[t]->e->dp.model != kShockCooling3;
+    for (int t = 0; t < n && one_launch; ++t) {
+        const DevProblem& ip = items[t].pb;
+        pop_lds = std::max(pop_lds, (kExpTabSize + 16) * sizeof(double) + (size_t)ip.stage_d2 * sizeof(double2) +
+                                        (size_t)pop_group * (kPopScratch + 4 * kPopMaxParts) * sizeof(double) +
+                                        (size_t)pop_group * ip.n_epochs * sizeof(double2));
+    }
+    one_launch = one_launch && pop_lds <= kLdsPerCU;
     LCF_HIP(hipSetDevice(s0->e->device));
     MultiItem* ditems = nullptr;
     LCF_HIP(hipMalloc((void**)&ditems, (size_t)n * sizeof(MultiItem)));
     hipStream_t st = s0->e->stream;
     hipError_t err = hipMemcpyAsync(ditems, items.data(), (size_t)n * sizeof(MultiItem), hipMemcpyHostToDevice, st);
     const int nh = s0->ds.n_half;
-    const DevProblem& p0 = s0->e->dp;
     hipEvent_t ev0 = s0->ev0, ev1 = s0->ev1;
     if (err == hipSuccess) err = hipEventRecord(ev0, st);
     const dim3 gs((unsigned)(nh * max_nec), (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
     const dim3 bs(thermal && max_epochs > kFewEpochs ? kBlock : 64), bp(kBlock);
-    for (int64_t k = 0; k <= 2 * n_steps && err == hipSuccess; ++k) {
+    if (one_launch) {
+        const dim3 gq((unsigned)((nh + pop_group - 1) / pop_group), (unsigned)n), bq(64 * pop_group);
+        for (int64_t k = 0; k < 2 * n_steps && err == hipSuccess; ++k) {
+            for (int t = 0; t < n && err == hipSuccess; ++t)
+                if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
+            if (err != hipSuccess) break;
+#define LCF_POP2(ND, G) do { allow_lds(k_pop<ND, 1, G>, pop_lds);                                                   \
+                             hipLaunchKernelGGL((k_pop<ND, 1, G>), gq, bq, pop_lds, st, ditems, (long long)k); } while (0)
+#define LCF_POP(ND) LCF_POP2(ND, pop_group)
+            switch (same_dim) {
+                case 4: LCF_POP(4); break;
+                case 5: LCF_POP(5); break;
+                case 6: LCF_POP(6); break;
+                case 8: LCF_POP(8); break;
+                default: LCF_POP(0); break;
+            }
+#undef LCF_POP2
+#undef LCF_POP
+            for (int t = 0; t < n && err == hipSuccess; ++t) {
+                if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
+                if (leave_half_step(ss[t], st) != LCF_OK) err = hipErrorUnknown;
+            }
+            if (err == hipSuccess) err = hipGetLastError();
+        }
+    }
+    for (int64_t k = 0; !one_launch && k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
         if (have_next)  // every transient's block of draw records resident for this stream
@@ -2886,6 +3069,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         ss[t]->g_next = g + 2 * n_steps;
         ss[t]->pending = false;
         ss[t]->last_ms = ms;
+        ss[t]->last_kernel = one_launch ? LCF_KERNEL_POPULATION : LCF_KERNEL_POPULATION_PHASES;
     }
     for (int t = 0; t < n; ++t)
         if (lcf_status r = lcf_sampler_check(ss[t])) return r;

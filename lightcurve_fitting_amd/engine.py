@@ -102,6 +102,7 @@ SIGNATURES = [
     ('lcf_sampler_newlp_ptr', C.c_void_p, [C.c_void_p]),
     ('lcf_sampler_one_launch', C.c_int32, [C.c_void_p]),
     ('lcf_sampler_set_half_step_kernel', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    ('lcf_sampler_last_run_kernel', C.c_int32, [C.c_void_p]),
     ('lcf_sampler_half_step_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_rows_ptr', C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
@@ -423,6 +424,12 @@ class NativeSampler:
     def one_launch(self):
         """True if a half-step of this sampler is a single kernel launch (see ``lcf_sampler_one_launch``)."""
         return bool(self._lib.lcf_sampler_one_launch(self._h))
+
+    def last_run_kernel(self):
+        """What executed the half-steps of the last run: 'phases' | 'fused' | 'solo' | 'population' (one launch per
+        half-step for all transients of a population) | 'population-phases' (None: no run yet)."""
+        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases'}.get(
+            self._lib.lcf_sampler_last_run_kernel(self._h))
 
     def set_half_step_kernel(self, choice='auto'):
         """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'fused' | 'phases'; same chain bit

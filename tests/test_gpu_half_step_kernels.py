@@ -201,3 +201,39 @@ def test_peer_mailboxes_between_processes(ranks):
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['every_rank_equals_the_single_gpu_chain'] and line['peer_mailboxes_connected_on_every_rank']
+
+
+@pytest.mark.parametrize('nwalkers', [21, 64])
+def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
+    """Population mode with shared epochs runs ONE launch per half-step for all transients (k_pop: a workgroup per four
+    proposals, accept test included).  Its chains are bitwise those of the two-launch path (LCF_NO_POP=1), and the
+    oracle-driven chain of a transient; 21 walkers = 11 slots per half-step: a partly filled last workgroup and, in
+    every second half-step, an empty slot."""
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    problems, x0, pbs = [], {}, []
+    for k in range(4):
+        rng = np.random.default_rng(300 + k)
+        epochs = np.sort(rng.uniform(0.4, 9., 60 + 11 * k))
+        t, names = np.repeat(epochs, 6), list(np.tile(list('UBVgri'), len(epochs)))
+        bands = [O.band(n) for n in names]
+        truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1]) * rng.uniform(0.9, 1.1, 5)
+        om = ('ShockCooling', O.ShockCoolingOracle(0.))
+        ytrue = O.evaluate(om, t, bands, truth)
+        y, dy = ytrue * (1 + 0.05 * rng.standard_normal(len(t))), 0.05 * ytrue
+        priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+        pbs.append(dict(model=om, orc=None, t=t, bands=bands, y=y, dy=dy, priors=[p.descriptor() for p in priors]))
+        problems.append((M.ShockCooling(redshift=0.), lc_dict(t, names, y, dy), priors))
+        x0[k] = truth * (1 + 0.05 * rng.standard_normal((nwalkers, 5)))
+    chains = {}
+    for no_pop in (False, True):
+        if no_pop:
+            monkeypatch.setenv('LCF_NO_POP', '1')
+        pop = PopulationSampler(problems, nwalkers, seed=17)
+        pop.run_mcmc(x0, 6)
+        pop.run_mcmc(None, 3)
+        assert pop[0]._native.last_run_kernel() == ('population-phases' if no_pop else 'population')
+        chains[no_pop] = [(pop[k].get_chain(), pop[k].get_log_prob(), pop[k].acceptance_fraction) for k in range(4)]
+    for a, b in zip(chains[False], chains[True]):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pbs[2]), x0[2], 9, 17 + 2)
+    assert relerr(chains[False][2][0], ref) < 1e-9 and relerr(chains[False][2][1], ref_lp) < 1e-9

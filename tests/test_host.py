@@ -306,3 +306,9 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
         shared_epochs = re.search(r'k_(solo|fused)ILi\dELi1ELb1E', k) or re.search(r'k_pointsILi1ELi0ELb1ELb1E', k)
         assert int(f['SGPRs Spill']) <= (128 if shared_epochs else 192), (k, f)
         assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
+    # population mode's one launch per half-step, in the dimensions with their own instantiation
+    pops = [k for k in blocks if re.search(r'k_popILi[4568]ELi1ELi4E', k)]
+    assert len(pops) == 4, sorted(blocks)[:5]
+    for k in pops:
+        f = blocks[k]
+        assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0 and int(f['Occupancy']) >= 4, (k, f)

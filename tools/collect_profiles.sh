@@ -13,7 +13,7 @@ mkdir -p $OUT $FINAL
 cd /tmp && export TMPDIR=/tmp
 declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
 declare -A PSTEPS=( [mcmc]=5 [companion]=2 [population]=3 [sed]=1 )
-declare -A KERNEL=( [mcmc]=k_solo [companion]=k_solo [population]=k_points_multi [sed]=k_sed )
+declare -A KERNEL=( [mcmc]=k_solo [companion]=k_solo [population]=k_pop [sed]=k_sed )
 declare -A PTAG=( [mcmc]=k_solo_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
 for W in mcmc companion population sed; do
   echo "== $W: kernel trace"
