@@ -89,9 +89,11 @@ def parse_args(argv=None):
     ap.add_argument('--variant', type=int, default=3,
                     help='band sum: 3 = interpolated ln S(ln T) per filter where proved, Gauss-compressed tables elsewhere '
                          '(default), 2 = Gauss-compressed tables, 1 = the full tables, 0 = libm')
-    ap.add_argument('--collective', choices=['allgather', 'peers'], default='allgather',
-                    help='N > 1: how the ranks exchange the rows of a half-step: one RCCL all-gather (default), or direct '
-                         "stores into every rank's mailbox over IPC-mapped memory (no collective; experimental)")
+    ap.add_argument('--collective', choices=['auto', 'allgather', 'peers'], default='auto',
+                    help='N > 1: how the ranks exchange the rows of a half-step: one RCCL all-gather, or direct stores '
+                         "into every rank's mailbox over IPC-mapped memory (no collective).  auto (default): both are "
+                         'tried for a few untimed steps -- a driver that fails, or whose ranks end in different states, '
+                         'is out -- and the faster one runs the timed steps; the line says which and why')
     ap.add_argument('--launch-check', action='store_true',
                     help='only start the ranks, let them find each other (gloo) and print what they saw')
     return ap.parse_args(argv)
@@ -158,8 +160,8 @@ def launch_check(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({'launch_check': True, 'n_gpus': world, 'ranks_seen': seen,
-                          'spawned_by_bench': os.environ.get('LCF_BENCH_SPAWNED') == '1'}), flush=True)
+        emit({'launch_check': True, 'n_gpus': world, 'ranks_seen': seen,
+              'spawned_by_bench': os.environ.get('LCF_BENCH_SPAWNED') == '1'})
 
 
 def max_over_ranks(dist, elapsed):
@@ -188,6 +190,46 @@ def timed_run(sampler, dist, warmup, steps, x0):
     sampler.run_mcmc(None, steps, store=False)        # returns after the device has finished
     barrier()
     return max_over_ranks(dist, time.perf_counter() - t0)
+
+
+def pick_collective(make_sampler, dist, x0, args):
+    """N > 1: the sampler that runs the timed steps.  `--collective auto` tries the peer mailboxes and the all-gather
+    for a few untimed steps each: a driver that raises on any rank (its waits are bounded), that silently fell back, or
+    that leaves the ranks with different replicas of the ensemble is out; of the rest the faster one is taken.  Nothing
+    collective happens inside the try blocks, so a failure on one rank cannot leave the others waiting."""
+    if dist is None or args.collective != 'auto':
+        return make_sampler(None if dist is None else args.collective), None
+    import torch
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    probe_steps = max(10, min(50, args.warmup * 4))
+    weights = np.cos(np.arange(x0.size, dtype=np.float64)).reshape(x0.shape)
+    report, best = {}, None
+    for mode in ('peers', 'allgather'):
+        seconds, checksum, why, s = float('inf'), 0., None, None
+        try:
+            s = make_sampler(mode)
+            s.run_mcmc(x0, 5, store=False)
+            t0 = time.perf_counter()
+            state = s.run_mcmc(None, probe_steps, store=False)   # (returns after the device has finished)
+            seconds = time.perf_counter() - t0
+            if mode == 'peers' and not s._peers:
+                seconds, why = float('inf'), 'the mailboxes could not be connected'
+            checksum = float(np.sum(np.asarray(state[0]) * weights))
+        except Exception as exc:  # noqa: BLE001
+            seconds, why = float('inf'), f'{type(exc).__name__}: {exc}'[:200]
+        agg = torch.tensor([seconds if np.isfinite(seconds) else 1e30, checksum, -checksum], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.MAX)
+        worst, hi, lo = float(agg[0]), float(agg[1]), -float(agg[2])
+        ok = worst < 1e29 and hi == lo
+        report[mode] = {'ok': ok, 'ms_per_step': 1e3 * worst / probe_steps if worst < 1e29 else None,
+                        'replicas_agree': hi == lo, 'note': why}
+        if ok and (best is None or worst < best[0]):
+            best = (worst, mode, s)
+    if best is None:
+        raise RuntimeError(f'no multi-GPU driver completed its probe: {report}')
+    report['selected'] = best[1]
+    report['probe_steps'] = probe_steps
+    return best[2], report
 
 
 def collective_info(sampler, dist, world):
@@ -421,11 +463,14 @@ def run_mcmc(args):
     engine._variant = args.variant
     scaling = args.scaling or 'weak'
     n_walkers = WALKERS_PER_GPU * (world if scaling == 'weak' else 1)
-    sampler = EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=args.collective)
     x0 = initial_walkers(n_walkers)
+    sampler, probe = pick_collective(lambda mode: EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=mode), dist,
+                                     x0, args)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = n_walkers * args.steps / elapsed
     coll = collective_info(sampler, dist, world)
+    if coll is not None:
+        coll['probe'] = probe
     if rank == 0:
         # dominant kernel alone, at this rank's share of a half-step when the run is sharded over the GPUs
         per_rank = n_walkers // world
@@ -461,7 +506,7 @@ def run_mcmc(args):
                 out['cpu_baseline_c'] = cpu_baseline_c(lc)
             except Exception as exc:  # noqa: BLE001 - the extra reference point must never break the bench line
                 out['cpu_baseline_c'] = {'error': repr(exc)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -518,11 +563,14 @@ def run_companion(args):
     nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
     engine = model.engine_for(lc, priors=priors)
     engine._variant = 3
-    sampler = EnsembleSampler(nw, 8, engine, seed=SEED, collective=args.collective)
     x0 = companion_walkers(nw)
+    sampler, probe = pick_collective(lambda mode: EnsembleSampler(nw, 8, engine, seed=SEED, collective=mode), dist, x0,
+                                     args)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = nw * args.steps / elapsed
     coll = collective_info(sampler, dist, world)
+    if coll is not None:
+        coll['probe'] = probe
     if rank == 0:
         per_rank = nw // world
         kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7, reps=200)
@@ -547,7 +595,7 @@ def run_companion(args):
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_companion(lc, lum0)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -632,7 +680,7 @@ def run_population(args):
                                    'sample': f'{n} per-walker log-likelihood evaluations of one transient (600 points, '
                                              f'oracle in reference-shaped mode), {dt:.1f} s on 1 of {os.cpu_count()} cores'}
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -699,7 +747,26 @@ def run_sed(args):
                                 'sample': f'{n} candidate evaluations (6 filters each, oracle in reference-shaped mode), '
                                           f'{dt:.1f} s on 1 of {os.cpu_count()} host cores'}
         line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
-    print(json.dumps(line), flush=True)
+    emit(line)
+
+
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (gloo's "[Gloo] Rank 0 is connected ...",
+    RCCL's version banner, both from C++): from here on descriptor 1 is the process's stderr, and the result line goes
+    to the saved descriptor."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + '\n').encode()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, data)
 
 
 def main():
@@ -710,6 +777,7 @@ def main():
         # no launcher: start the ranks here, BEFORE anything in this process initialises the GPU (torch is not even
         # imported in the parent)
         sys.exit(spawn_ranks(args.gpus))
+    keep_stdout_for_the_result()
     if args.launch_check:
         return launch_check(args)
     {'mcmc': run_mcmc, 'companion': run_companion, 'population': run_population, 'sed': run_sed}[args.workload](args)

@@ -46,7 +46,13 @@ def test_two_rank_bench_line_on_one_device(workload):
                           '--no-cpu-baseline'] + extra, env=_clean_env(LCF_BENCH_ONE_DEVICE='1'), capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert len(out.stdout.splitlines()) == 1, out.stdout[:500]   # ONE line: what libraries print goes to stderr
+    line = json.loads(out.stdout)
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['steps'] == 6
-    assert line['collective']['group_ranks'] == 2 and 'gloo' in line['collective']['driver']
+    # both multi-rank drivers are probed (peer mailboxes over IPC, collectives -- gloo here), the faster one is timed
+    coll = line['collective']
+    probe = coll['probe']
+    assert probe['peers']['ok'] and probe['allgather']['ok'] and probe['peers']['replicas_agree']
+    assert probe['selected'] in ('peers', 'allgather') and coll.get('group_ranks', 2) == 2
+    assert ('mailboxes' in coll['driver']) == (probe['selected'] == 'peers')
     assert 0 < line['roofline']['frac'] <= 1
