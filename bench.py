@@ -89,11 +89,13 @@ def parse_args(argv=None):
     ap.add_argument('--variant', type=int, default=3,
                     help='band sum: 3 = interpolated ln S(ln T) per filter where proved, Gauss-compressed tables elsewhere '
                          '(default), 2 = Gauss-compressed tables, 1 = the full tables, 0 = libm')
-    ap.add_argument('--collective', choices=['auto', 'allgather', 'peers'], default='auto',
-                    help='N > 1: how the ranks exchange the rows of a half-step: one RCCL all-gather, or direct stores '
-                         "into every rank's mailbox over IPC-mapped memory (no collective).  auto (default): both are "
-                         'tried for a few untimed steps -- a driver that fails, or whose ranks end in different states, '
-                         'is out -- and the faster one runs the timed steps; the line says which and why')
+    ap.add_argument('--collective', choices=['auto', 'allgather', 'peers', 'rows'], default='auto',
+                    help='N > 1: how the ranks work together.  rows: every rank moves its share of the walkers itself '
+                         "(k_solo) and stores their new rows into every rank's board over IPC-mapped memory; peers: every "
+                         'rank evaluates its share (k_fused), stores partial sums into every mailbox and replicates the '
+                         'bookkeeping; allgather: the same with one RCCL all-gather per half-step.  auto (default): all '
+                         'three are tried for a few untimed steps -- a driver that fails, or whose ranks end in different '
+                         'states, is out -- and the fastest one runs the timed steps; the line says which and why')
     ap.add_argument('--launch-check', action='store_true',
                     help='only start the ranks, let them find each other (gloo) and print what they saw')
     return ap.parse_args(argv)
@@ -204,7 +206,7 @@ def pick_collective(make_sampler, dist, x0, args):
     probe_steps = max(10, min(50, args.warmup * 4))
     weights = np.cos(np.arange(x0.size, dtype=np.float64)).reshape(x0.shape)
     report, best = {}, None
-    for mode in ('peers', 'allgather'):
+    for mode in ('rows', 'peers', 'allgather'):
         seconds, checksum, why, s = float('inf'), 0., None, None
         try:
             s = make_sampler(mode)
@@ -212,8 +214,8 @@ def pick_collective(make_sampler, dist, x0, args):
             t0 = time.perf_counter()
             state = s.run_mcmc(None, probe_steps, store=False)   # (returns after the device has finished)
             seconds = time.perf_counter() - t0
-            if mode == 'peers' and not s._peers:
-                seconds, why = float('inf'), 'the mailboxes could not be connected'
+            if (mode == 'peers' and not s._peers) or (mode == 'rows' and not s._boards):
+                seconds, why = float('inf'), 'the peer memory could not be connected'
             checksum = float(np.sum(np.asarray(state[0]) * weights))
         except Exception as exc:  # noqa: BLE001
             seconds, why = float('inf'), f'{type(exc).__name__}: {exc}'[:200]
@@ -238,6 +240,12 @@ def collective_info(sampler, dist, world):
         return None
     n_half = (sampler.nwalkers + 1) // 2
     rows = sampler._native.rows_ptr()[1]
+    if sampler.collective == 'rows' and sampler._boards:
+        return {'driver': 'row boards: every rank moves its share of the walkers with k_solo and stores their new rows '
+                          "(position, log-posterior, acceptance count) straight into all ranks' boards (IPC-mapped device "
+                          'memory); no collective, no launch between half-steps, nothing replicated',
+                'rccl_comm_ranks': None, 'group_ranks': dist.get_world_size(), 'allgather_us': None,
+                'payload_bytes_per_rank': 16 * (sampler.ndim + 2) * n_half // world}
     if sampler.collective == 'peers' and sampler._peers:
         return {'driver': "peer mailboxes: every rank stores its shard's rows straight into all ranks' mailboxes "
                           '(IPC-mapped device memory) and polls its own; no collective, no launch between half-steps',

@@ -292,6 +292,24 @@ lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_s
 lcf_status lcf_sampler_run_peers_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                                        const int32_t* perm, int32_t store_chain);
 
+/* Row boards: the sharded run in which nothing is replicated.  Rank r evaluates, accepts and commits the proposals
+ * [r w, (r + 1) w) of every half-step with the one-workgroup-per-proposal kernel (k_solo) and stores each walker's new
+ * row -- position, log-posterior, acceptance count, as {32 data bits, 32-bit half-step tag} words -- straight into
+ * EVERY rank's board (uncached device memory, mapped through IPC: xGMI writes on a node); the serial head of a later
+ * half-step polls its own board for exactly the versions of the two rows it needs.  No collective, no launch between
+ * half-steps, no work about other ranks' walkers; every wait is bounded (0.5 s, then LCF_ERR_STATE).  When the run
+ * ends, state, acceptance counts and (if stored) the chain are complete on every rank.  Same chain as every other
+ * driver, bit for bit.  export / connect as for the mailboxes (local_ptrs: ranks emulated inside one process).
+ * lcf_sampler_run_rows is collective in effect: same arguments on every rank, called after ALL ranks have returned
+ * from the previous run, on samplers that have seen the same sequence of runs. */
+lcf_status lcf_sampler_board_export(lcf_sampler* s, lcf_ipc_handle* out, void** local_ptr);
+lcf_status lcf_sampler_board_connect(lcf_sampler* s, int32_t n_ranks, int32_t rank, const lcf_ipc_handle* handles,
+                                     void* const* local_ptrs);
+lcf_status lcf_sampler_run_rows(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                const int32_t* perm, int32_t store_chain);
+lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                      const int32_t* perm, int32_t store_chain);
+
 /* ---- per-epoch blackbody SED likelihood (bolometric.py:154-164: spectrum_mcmc's inner log_posterior) --------- */
 /* For every epoch e, observations ep_off[e] .. ep_off[e+1]-1 (filter index, luminosity density y, uncertainty dy);
  * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged

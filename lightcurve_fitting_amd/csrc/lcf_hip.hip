@@ -451,7 +451,7 @@ struct DrawRec {
     double z;          // stretch factor
     double zl;         // (n_dim - 1) ln z
     double lnu;        // ln u
-    double pad;
+    int wage, page;    // half-steps since the walker / the partner last moved (1..3; 0 without slot bookkeeping)
 };
 
 struct DevSampler {
@@ -476,6 +476,15 @@ struct DevSampler {
     // own copy.  mbox = this rank's, peer_mbox[r] = rank r's as mapped here (own included).
     unsigned long long* mbox;
     unsigned long long* peer_mbox[kMaxPeers];
+    // Row boards (multi-GPU, one workgroup per proposal: lcf_sampler_run_rows).  Every rank owns a board
+    // [kRing versions][n_walkers][n_dim + 2] of 16-byte entries in uncached memory -- a walker's position, its
+    // log-posterior and its acceptance count after each of its moves, tagged with the half-step -- followed by one
+    // progress word per rank, an abort word and four words that say what an aborted launch was waiting for.  The rank
+    // that moves a walker posts the row on EVERY rank's board; nobody else computes anything about that walker.
+    unsigned long long* board;
+    unsigned long long* peer_board[kMaxPeers];
+    unsigned int* done_count;   // workgroups of the current launch that have committed (ordinary device memory)
+    int n_board_ranks, board_rank;
 };
 
 // One float64 as two 8-byte granules {32 data bits, 32-bit generation tag}: an 8-byte store is the largest that
@@ -584,7 +593,8 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     if (i >= n_act) {
         d.wid = d.pid = d.wprev = d.pprev = -1;
         d.z = 1.;
-        d.zl = d.lnu = d.pad = 0.;
+        d.zl = d.lnu = 0.;
+        d.wage = d.page = 0;
         draws[idx] = d;
         return;
     }
@@ -606,7 +616,21 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
     d.z = z;
     d.zl = (double)(sm.n_dim - 1) * log(z);
     d.lnu = log(u01(s2[0], s2[1]));
-    d.pad = 0.;
+    // Every walker moves once per step, in one of its two half-steps: a walker that was not active in the half-step in
+    // front (half-step G - 1) moved in the one before it, or -- the walker of a step's SECOND half-step only -- three
+    // half-steps ago (first half of the previous step).  The sharded one-workgroup-per-proposal run waits for exactly
+    // that version of each row.  (Before the first step of a run every age points in front of the run: its start state.)
+    d.wage = d.page = 0;
+    if (slot_of) {
+        if (half == 0) {
+            d.wage = before[d.wid] >= 0 ? 1 : 2;
+            d.page = before[d.pid] >= 0 ? 1 : 2;
+        } else {
+            const int* two_back = slot_of + (size_t)(row * 2) * sm.n_walkers;  // second half of the previous step
+            d.wage = two_back[d.wid] >= 0 ? 2 : 3;
+            d.page = 1;
+        }
+    }
     draws[idx] = d;
 }
 
@@ -627,7 +651,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
     const int pp = (int)((g - 1) & 1), cp = (int)(g & 1);
     constexpr int kD = ND > 0 ? ND : kMaxDim;     // array extent
     const int nd = ND > 0 ? ND : sm.n_dim;         // trip count (constant when ND > 0)
-    DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0.};
+    DrawRec dr{0, 0, -1, -1, 1., 0., 0., 0, 0};
     if (have_next) dr = draws[i];
     const bool active = have_next && dr.wid >= 0;  // (an odd ensemble leaves the last slot of its second half-step empty)
     // --- roles: which accept test (if any) this lane evaluates ---
@@ -931,13 +955,130 @@ __device__ unsigned long long g_stamps[64 * 16];
 #define LCF_STAMP(W, k) do {} while (0)
 #endif
 
+// ---- row boards: tagged words in uncached memory ------------------------------------------------------------------
+// One float64 = two 8-byte granules {32 data bits, 32-bit tag}, tag = half-step after which the row holds + 1 (the LL
+// protocol of the mailboxes above); version ring of kRing half-steps.  Safe because (a) a reader asks for exactly the
+// version the draw record names (DrawRec::wage / page) and waits, bounded, until both granules carry its tag; (b) no rank
+// starts half-step G before every rank has finished G - 2 (progress words): half-steps G - 1 and G are the only ones in
+// flight anywhere, they read versions >= G - 3 and write G and G + 1, so eight versions are never overrun.
+constexpr int kRing = 8;
+constexpr int kBoardTail = kMaxPeers + 1 + 4;   // 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis
+
+__device__ inline size_t board_rows_words(const DevSampler& sm) {
+    return (size_t)kRing * sm.n_walkers * (sm.n_dim + 2) * 2;   // 8-byte words
+}
+__device__ inline unsigned long long* board_entry(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid,
+                                                  int col) {
+    return board + 2 * ((((size_t)(tag & (kRing - 1)) * sm.n_walkers) + wid) * (sm.n_dim + 2) + col);
+}
+__device__ inline unsigned int* board_progress(unsigned long long* board, const DevSampler& sm) {
+    return reinterpret_cast<unsigned int*>(board + board_rows_words(sm));
+}
+__device__ inline void board_post(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid, int col, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    unsigned long long* p = board_entry(board, sm, tag, wid, col);
+    __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline bool board_aborted(const DevSampler& sm) {
+    return __hip_atomic_load(board_progress(sm.board, sm) + kMaxPeers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
+// (what: 1 = a row, a = tag, b = walker, c = column; 2 = the progress words, a = half-step, b = rank that is behind)
+__device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsigned int a, unsigned int b, unsigned int c) {
+    unsigned int* flag = board_progress(sm.board, sm) + kMaxPeers;
+    if (atomicCAS_system(flag, 0u, 1u) == 0u) {   // the first one to give up says what it was waiting for
+        __hip_atomic_store(flag + 1, what, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag + 2, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag + 3, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag + 4, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    atomicOr(sm.err, 2);
+}
+// The number with tag `tag` from this rank's board, once it is there (bounded wait: 0.5 s, then the launch is aborted
+// and the run ends with an error; NaN after an abort).
+__device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col) {
+    const unsigned long long* p = board_entry(sm.board, sm, tag, wid, col);
+    const unsigned long long t0 = wall_clock64();
+    for (int spin = 0;; ++spin) {
+        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned int)(a >> 32) == tag && (unsigned int)(b >> 32) == tag)
+            return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+        if ((spin & 15) == 15) {
+            if (board_aborted(sm)) return qnan();
+            if (wall_clock64() - t0 > 50000000ull) {
+                board_abort(sm, 1u, tag, (unsigned int)wid, (unsigned int)col);
+                return qnan();
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// Version of a row a half-step G asks for: the walker's last move was `age` half-steps ago; rows nobody has moved in
+// this run carry the run's start tag.
+__device__ inline unsigned int board_tag(long long G, int age, long long g_run0) {
+    const long long t = G - age + 1;
+    return (unsigned int)(t < g_run0 ? g_run0 : t);
+}
+
+// A workgroup of this rank's launch of half-step G is through (committed and posted): the last one tells every rank.
+__device__ inline void board_launch_done(const DevSampler& sm, long long G) {
+    const unsigned int before = atomicAdd(sm.done_count, 1u);
+    if (before + 1u == gridDim.x) {
+        atomicExch(sm.done_count, 0u);   // (the next launch is behind this one in the stream)
+        for (int r = 0; r < sm.n_board_ranks; ++r)
+            __hip_atomic_store(board_progress(sm.peer_board[r], sm) + sm.board_rank, (unsigned int)(G + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Start of a run: this rank's complete state as version `tag` (= the run's first half-step: "the state in front of it")
+// on its OWN board; the abort word is cleared.  (Progress words are absolute half-step numbers and are never reset: a
+// faster rank may already have posted into this board.)
+__global__ void k_board_init(const DevSampler sm, unsigned int tag) {
+    const int cols = sm.n_dim + 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 5) __hip_atomic_store(board_progress(sm.board, sm) + kMaxPeers + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (idx >= (long long)sm.n_walkers * cols) return;
+    const int wid = (int)(idx / cols), col = (int)(idx % cols);
+    const double v = col < sm.n_dim ? sm.X[(size_t)wid * sm.n_dim + col] : col == sm.n_dim ? sm.LP[wid] : (double)sm.nacc[wid];
+    board_post(sm.board, sm, tag, wid, col, v);
+}
+
+// The rows of half-step G, as every rank posted them, into this rank's state (end of a run: `n_hs` = 2, the last step)
+// and / or into the chain (`to_chain`, every half-step of a run that stores it).  One wave per slot, lane = column.
+__global__ void k_board_collect(const DevSampler sm, long long G, long long row, const DrawRec* __restrict__ draws, int n_hs,
+                                int to_state, int to_chain) {
+    const int lane = threadIdx.x & 63, nd = sm.n_dim;
+    const long long item = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (item >= (long long)n_hs * sm.n_half) return;
+    const int h = (int)(item / sm.n_half);
+    const DrawRec dr = draws[item];
+    if (dr.wid < 0 || lane > nd + 1) return;
+    if (board_aborted(sm)) return;
+    const double v = board_take(sm, (unsigned int)(G + h + 1), dr.wid, lane);
+    if (to_state) {
+        if (lane < nd) sm.X[(size_t)dr.wid * nd + lane] = v;
+        else if (lane == nd) sm.LP[dr.wid] = v;
+        else sm.nacc[dr.wid] = (long long)v;
+    }
+    if (to_chain && sm.store_chain) {
+        if (lane < nd) sm.chain[((size_t)(row + h / 2) * sm.n_walkers + dr.wid) * nd + lane] = v;
+        else if (lane == nd) sm.chain_lp[(size_t)(row + h / 2) * sm.n_walkers + dr.wid] = v;
+    }
+}
+
 // The serial head of one proposal, executed by ONE wave (lane = 0..63): rows of the walker and of its partner ->
 // proposal -> logarithms (one parameter per lane) -> coefficients, log-prior; lane 0 leaves them in LDS: sc[0 .. kNCoef)
 // the coefficients, sc[kNCoef] the log-prior, sq the proposal, sx the walker's position and sx[kMaxDim] its
 // log-posterior.
-template <int ND>
+// BOARD: the rows come from this rank's row board instead of X / LP -- lanes 0 .. nd-1 poll the partner's position,
+// lanes 16 .. 16+nd+1 the walker's position, log-posterior and acceptance count (left in sx[kMaxDim + 1]), each for the
+// version the draw record names -- and are handed round by shuffles; everything after that is the same arithmetic.
+template <int ND, bool BOARD = false>
 __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
-                                              double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx) {
+                                              double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx,
+                                              long long G = 0, long long g_run0 = 0) {
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     PriorDev my_prior{0, 0, 0., 0., 0., 1.};
@@ -947,12 +1088,19 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
     double x[kD], q[kMaxDim], lq[kMaxDim];
 #pragma unroll
     for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
-    const double lp_i = sm.LP[dr.wid];
+    double got = 0.;
+    if (BOARD) {
+        const bool own = lane >= 16;
+        const int col = own ? lane - 16 : lane;
+        if (own ? col <= nd + 1 : col < nd)
+            got = board_take(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
+    }
+    const double lp_i = BOARD ? __shfl(got, 16 + nd, 64) : sm.LP[dr.wid];
     double arg = 1.;
 #pragma unroll
     for (int d = 0; d < kD; ++d) {
-        x[d] = d < nd ? xs[d] : 0.;
-        const double cj = d < nd ? cs_[d] : 0.;
+        x[d] = d < nd ? (BOARD ? __shfl(got, 16 + d, 64) : xs[d]) : 0.;
+        const double cj = d < nd ? (BOARD ? __shfl(got, d, 64) : cs_[d]) : 0.;
         q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
         if (lane == d && d < pb.n_par) arg = q[d];
     }
@@ -978,6 +1126,7 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
         for (int d = 0; d < kD; ++d)
             if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
     }
+    const double count = BOARD ? __shfl(got, 16 + nd + 1, 64) : 0.;
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
@@ -989,6 +1138,7 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
                 sx[d] = x[d];
             }
         sx[kMaxDim] = lp_i;
+        if (BOARD) sx[kMaxDim + 1] = count;   // the walker's acceptance count so far
     }
     LCF_STAMP(0, 5);
 }
@@ -1006,10 +1156,13 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
 // complementary colour, which this half-step does not move), so there is nothing to synchronise.
 constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // doubles: coefficients, log-prior, q, x
 
-template <int ND, int VARIANT, bool THERM, int NPARTS>
+// BOARD (multi-GPU, lcf_sampler_run_rows): the launch covers this rank's slots [slot_lo, slot_lo + gridDim.x) of
+// half-step G; rows come from this rank's row board and the commit posts the walker's new row on EVERY rank's board.
+// No rank computes anything about another rank's proposals, and nothing but these rows travels.
+template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false>
 __global__ __launch_bounds__(kBlock * NPARTS, LCF_WAVES)
 void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
-            const DrawRec* draws_next) {
+            const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
@@ -1020,18 +1173,22 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);  // coefficients, then log-prior
     double* sq = sc + kNCoef + 2;                                           // the proposal
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
+    int* sctl = reinterpret_cast<int*>(sc + kSoloScratch + 2);              // BOARD: [0] = 1: the launch is aborted
     double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
     constexpr int kThreads = kBlock * NPARTS;
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
-    const int tid = threadIdx.x, i = blockIdx.x;
+    const int tid = threadIdx.x, i = blockIdx.x + (BOARD ? slot_lo : 0);
     const bool reddened = pb.model == kShockCooling3;
     LCF_STAMP(0, 0);
     const DrawRec dr = draws[i];     // wave-uniform
-    if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
+    if (dr.wid < 0) {                // an odd ensemble's smaller colour leaves its last slot empty
+        if (BOARD && tid == 0) board_launch_done(sm, G);
+        return;
+    }
     LCF_STAMP(0, 1);
     if (tid < 64) {
-        proposal_head<ND>(pb, sm, dr, tid, sc, sq, sx);
+        proposal_head<ND, BOARD>(pb, sm, dr, tid, sc, sq, sx, G, g_run0);
     } else {
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
@@ -1043,9 +1200,32 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
         }
         if (!reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
         LCF_STAMP(1, 11);
+        if (BOARD && tid < 128) {
+            // In the shadow of the head: has every rank finished half-step G - 2 (lane = rank)?  has this rank given up?
+            const int lane = tid - 64;
+            const unsigned int* progress = board_progress(sm.board, sm);
+            const unsigned long long t0 = wall_clock64();
+            bool abort = false;
+            for (;;) {
+                bool ok = true;
+                if (G - 2 >= g_run0 && lane < sm.n_board_ranks)   // (earlier half-steps ended with an earlier run)
+                    ok = (int)(__hip_atomic_load(progress + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
+                               (unsigned int)(G - 1)) >= 0;
+                abort = board_aborted(sm);
+                if (__all(ok) || abort) break;
+                if (wall_clock64() - t0 > 50000000ull) {
+                    board_abort(sm, 2u, (unsigned int)G, (unsigned int)__builtin_ctzll(~__ballot(ok)), 0u);
+                    abort = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) sctl[0] = abort ? 1 : 0;
+        }
     }
     __syncthreads();
     LCF_STAMP(0, 6);
+    if (BOARD && sctl[0] != 0) return;   // (uniform: everybody reads the same word)
     const double lpr = sc[kNCoef];
     double term = 0.;
     const bool excluded = lpr == -INFINITY;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
@@ -1080,6 +1260,38 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     }
     __syncthreads();
     LCF_STAMP(0, 9);
+    if (BOARD) {
+        // ---- accept / reject by wave 0; lanes 0 .. nd+1 post the row (position, log-posterior, acceptance count) on every
+        // rank's board; this rank's X / LP / counts follow for its own walkers (the others' come from the board when
+        // the run ends, and the chain is written from the board)
+        if (tid >= 64) return;
+        double nlp = -INFINITY;
+        if (!excluded) {
+            double sum = pb.use_sigma ? 0. : pb.log_norm_const;
+            for (int k = 0; k < pb.n_parts; ++k) sum += (red[4 * k] + red[4 * k + 1]) + (red[4 * k + 2] + red[4 * k + 3]);
+            nlp = lpr - 0.5 * sum;
+        }
+        const double lp_i = sx[kMaxDim];
+        const bool ok = (dr.zl + nlp - lp_i) > dr.lnu;
+        const double count = sx[kMaxDim + 1] + (ok ? 1. : 0.);
+        if (tid <= nd + 1) {
+            const double v = tid < nd ? (ok ? sq[tid] : sx[tid]) : tid == nd ? (ok ? nlp : lp_i) : count;
+#pragma unroll
+            for (int r = 0; r < kMaxPeers; ++r)
+                if (r < sm.n_board_ranks) board_post(sm.peer_board[r], sm, (unsigned int)(G + 1), dr.wid, tid, v);
+            if (tid < nd)
+                sm.X[(size_t)dr.wid * nd + tid] = v;
+            else if (tid == nd)
+                sm.LP[dr.wid] = v;
+            else
+                sm.nacc[dr.wid] = (long long)v;
+        }
+        if (tid == 0) {
+            if (nlp != nlp) atomicOr(sm.err, 1);
+            board_launch_done(sm, G);
+        }
+        return;
+    }
     if (tid != 0) return;
     // ---- accept / reject and commit (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move)
     double nlp = -INFINITY;
@@ -1207,7 +1419,7 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
         double* sq = sc + kNCoef + 2;
         double* sx = sq + kMaxDim + (kMaxDim & 1);
         const int slot = slot0 + wave;
-        DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0.};
+        DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0, 0};
         if (slot < nh) dr = item_rows(it, rel)[slot];     // wave-uniform
         const bool active = dr.wid >= 0;  // (an odd ensemble's smaller colour leaves its last slot empty)
         if (active) proposal_head<ND>(pb, sm, dr, lane, sc, sq, sx);
@@ -1986,6 +2198,12 @@ struct lcf_sampler {
     int half_step_kernel = LCF_HALF_STEP_AUTO;
     int last_kernel = -1;     // what the last run's half-steps were (lcf_sampler_last_run_kernel)
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
+    void* board_mem = nullptr;               // this rank's row board (uncached device memory), see DevSampler
+    std::vector<void*> board_opened;         // peers' boards mapped through IPC
+    size_t board_bytes() const {
+        return (size_t)kRing * ds.n_walkers * (ds.n_dim + 2) * 2 * sizeof(unsigned long long) +
+               (size_t)kBoardTail * sizeof(unsigned int);
+    }
     std::vector<void*> opened;               // peers' mailboxes mapped through IPC
     int peer_ranks = 0, peer_rank = 0;
     // Snapshot of (error flag, positions, log-posteriors, acceptance counts) in pinned host memory, copied behind the
@@ -2007,6 +2225,8 @@ struct lcf_sampler {
         free_blocks();
         for (void* p : opened) hipIpcCloseMemHandle(p);
         if (mailbox) hipFree(mailbox);
+        for (void* p : board_opened) hipIpcCloseMemHandle(p);
+        if (board_mem) hipFree(board_mem);
         if (snap) hipHostFree(snap);
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
@@ -2267,7 +2487,8 @@ bool solo_eligible(const lcf_sampler* s) {
 }
 
 // One half-step of a single-GPU run: ONE launch, one workgroup per proposal, accept test and commit included.
-lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
+// `board`: this rank's slots [lo, hi) only, rows from / to the row boards (lcf_sampler_run_rows).
+lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board = false, int lo = 0, int hi = 0) {
     lcf_engine* e = s->e;
     const DevSampler& ds = s->ds;
     if (lcf_status r = enter_half_step(s, rel, st)) return r;
@@ -2275,20 +2496,25 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
     const bool next_here = rel + 1 < 2 * s->run_steps && s->block_of_step((rel + 1) / 2) == s->blk_current;
     const DrawRec* draws_next = next_here ? draws + ds.n_half : nullptr;
     const size_t lds = solo_lds_bytes(e);
-    const long long row = rel / 2;
-    const dim3 grid((unsigned)ds.n_half);
-#define LCF_SOLO4(ND, V, T, NP)                                                                                       \
+    const long long row = rel / 2, G = s->g_run0 + rel, g_run0 = s->g_run0;
+    const dim3 grid((unsigned)(board ? hi - lo : ds.n_half));
+    if (board && hi <= lo) return leave_half_step(s, st);
+#define LCF_SOLO5(ND, V, T, NP, B)                                                                                    \
     do {                                                                                                              \
         if (lds > 64 * 1024) {                                                                                        \
             static bool raised = false; /* per instantiation: allow more than the default 64 KiB of dynamic LDS */   \
             if (!raised) {                                                                                            \
-                LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP>,                                        \
+                LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP, B>,                                     \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));             \
                 raised = true;                                                                                        \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_solo<ND, V, T, NP>), grid, dim3(kBlock * NP), lds, st, e->dp, ds, row, draws,           \
-                           draws_next);                                                                               \
+        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B>), grid, dim3(kBlock * NP), lds, st, e->dp, ds, row, draws,        \
+                           draws_next, G, g_run0, lo);                                                                \
+    } while (0)
+#define LCF_SOLO4(ND, V, T, NP)                                                                                       \
+    do {                                                                                                              \
+        if (board) LCF_SOLO5(ND, V, T, NP, true); else LCF_SOLO5(ND, V, T, NP, false);                                \
     } while (0)
     // workgroups of 512 threads (up to two parts) or 1024 (three or four)
 #define LCF_SOLO3(ND, V, T)                                                                                           \
@@ -2308,6 +2534,7 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st) {
 #undef LCF_SOLO
 #undef LCF_SOLO3
 #undef LCF_SOLO4
+#undef LCF_SOLO5
     LCF_HIP(hipGetLastError());
     return leave_half_step(s, st);
 }
@@ -2628,7 +2855,23 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (lcf_status st = settle(s)) return st;
     int err = 0;
     std::memcpy(&err, s->snap, sizeof(int));
-    if (err & 2) return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
+    if (err & 2) {
+        unsigned int w[5] = {0, 0, 0, 0, 0};
+        if (s->board_mem)
+            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - 5 * sizeof(unsigned int), sizeof w,
+                      hipMemcpyDeviceToHost);
+        if (w[0]) {
+            char msg[200];
+            if (w[1] == 1)
+                std::snprintf(msg, sizeof msg, "row-board run: version %u of walker %u (column %u) was not posted within "
+                              "0.5 s: a rank is missing or behind", w[2], w[3], w[4]);
+            else
+                std::snprintf(msg, sizeof msg, "row-board run: half-step %u waited 0.5 s for rank %u to finish half-step "
+                              "%u", w[2], w[3], w[2] - 2);
+            return fail(LCF_ERR_STATE, msg);
+        }
+        return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
+    }
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;
 }
@@ -2862,6 +3105,119 @@ lcf_status lcf_sampler_run_peers_async(lcf_sampler* s, int64_t first_step, int64
 lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                                  const int32_t* perm, int32_t store_chain) {
     if (lcf_status st = lcf_sampler_run_peers_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
+    return lcf_sampler_wait(s);
+}
+
+// ---- multi-GPU without replicated bookkeeping: rows over the boards (lcf_sampler_run_rows) ---------------------------
+}  // extern "C"
+
+namespace {
+lcf_status board_alloc(lcf_sampler* s) {
+    if (s->board_mem) return LCF_OK;
+    LCF_HIP(hipSetDevice(s->e->device));
+    // uncached (fine-grained) device memory: peers' stores over the fabric and this rank's polls meet in memory
+    LCF_HIP(hipExtMallocWithFlags(&s->board_mem, s->board_bytes(), hipDeviceMallocUncached));
+    LCF_HIP(hipMemset(s->board_mem, 0, s->board_bytes()));  // tag 0: no version (half-steps are numbered from 2)
+    if (!s->ds.done_count) {
+        if (lcf_status st = dalloc(&s->ds.done_count, 1, s->owned)) return st;
+        LCF_HIP(hipMemset(s->ds.done_count, 0, sizeof(unsigned int)));
+    }
+    s->ds.board = static_cast<unsigned long long*>(s->board_mem);
+    return LCF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+lcf_status lcf_sampler_board_export(lcf_sampler* s, lcf_ipc_handle* out, void** local_ptr) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (lcf_status st = board_alloc(s)) return st;
+    if (out) {
+        hipIpcMemHandle_t h;
+        LCF_HIP(hipIpcGetMemHandle(&h, s->board_mem));
+        std::memset(out, 0, sizeof(*out));
+        std::memcpy(out, &h, sizeof(h));
+    }
+    if (local_ptr) *local_ptr = s->board_mem;
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_board_connect(lcf_sampler* s, int32_t n_ranks, int32_t rank, const lcf_ipc_handle* handles,
+                                     void* const* local_ptrs) {
+    if (!s || n_ranks < 1 || n_ranks > kMaxPeers || rank < 0 || rank >= n_ranks || (!handles && !local_ptrs))
+        return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument (at most 8 ranks)");
+    if (s->ds.n_half % n_ranks)
+        return fail(LCF_ERR_INVALID_ARGUMENT, "the slots of a half-step must divide evenly over the ranks");
+    if (!solo_eligible(s))
+        return fail(LCF_ERR_UNSUPPORTED, "row-board runs need the one-workgroup-per-proposal half-step (k_solo)");
+    if (lcf_status st = board_alloc(s)) return st;
+    LCF_HIP(hipSetDevice(s->e->device));
+    for (int r = 0; r < n_ranks; ++r) {
+        void* p = nullptr;
+        if (r == rank) {
+            p = s->board_mem;
+        } else if (local_ptrs) {  // ranks emulated inside one process: plain device pointers
+            p = local_ptrs[r];
+        } else {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, &handles[r], sizeof(h));
+            LCF_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            s->board_opened.push_back(p);
+        }
+        if (!p) return fail(LCF_ERR_INVALID_ARGUMENT, "null peer board");
+        s->ds.peer_board[r] = static_cast<unsigned long long*>(p);
+    }
+    s->ds.n_board_ranks = n_ranks;
+    s->ds.board_rank = rank;
+    return LCF_OK;
+}
+
+// The sharded run in which nothing is replicated: rank r evaluates, accepts and commits the proposals
+// [r w, (r + 1) w) of every half-step with k_solo and posts each walker's new row (position, log-posterior, acceptance
+// count) on every rank's board; the serial head of a later half-step polls its own board for the rows it needs.  No
+// collective, no launch between half-steps, no work about other ranks' walkers.  When the run ends every rank takes
+// the last step's rows of ALL walkers from its board, so state, acceptance counts and (if stored) the chain are
+// complete on every rank.  Collective in effect: every rank calls it with the same arguments, after ALL ranks have
+// returned from the previous run (the caller's barrier); the ranks' samplers must have seen the same sequence of runs.
+lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                      const int32_t* perm, int32_t store_chain) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->ds.n_board_ranks < 1) return fail(LCF_ERR_STATE, "lcf_sampler_board_connect must be called first");
+    if (!solo_eligible(s))
+        return fail(LCF_ERR_UNSUPPORTED, "row-board runs need the one-workgroup-per-proposal half-step (k_solo)");
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, true)) return st;
+    hipStream_t st = s->e->stream;
+    DevSampler& ds = s->ds;
+    const int width = ds.n_half / ds.n_board_ranks, lo = ds.board_rank * width, hi = lo + width;
+    s->last_kernel = LCF_KERNEL_SOLO;
+    LCF_HIP(hipEventRecord(s->ev0, st));
+    const long long cells = (long long)ds.n_walkers * (ds.n_dim + 2);
+    hipLaunchKernelGGL(k_board_init, dim3((unsigned)((std::max<long long>(cells, 5) + 255) / 256)), dim3(256), 0, st, ds,
+                       (unsigned int)s->g_run0);
+    LCF_HIP(hipGetLastError());
+    const unsigned collect_blocks = (unsigned)((ds.n_half + 3) / 4);
+    for (int64_t k = 0; k < 2 * n_steps; ++k) {
+        if (lcf_status r = launch_solo(s, k, st, true, lo, hi)) return r;
+        if (store_chain) {  // the rows of this half-step, from every rank, into the chain
+            hipLaunchKernelGGL(k_board_collect, dim3(collect_blocks), dim3(256), 0, st, ds, (long long)(s->g_run0 + k),
+                               (long long)(k / 2), s->rows(k), 1, 0, 1);
+            LCF_HIP(hipGetLastError());
+        }
+    }
+    if (n_steps > 0) {  // the last step's rows of all walkers into X / LP / counts
+        const long long k = 2 * (n_steps - 1);
+        hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds, (long long)(s->g_run0 + k),
+                           (long long)(k / 2), s->rows(k), 2, 1, 0);
+        LCF_HIP(hipGetLastError());
+    }
+    s->g_next += 2 * n_steps;
+    LCF_HIP(hipEventRecord(s->ev1, st));
+    return enqueue_snapshot(s);
+}
+
+lcf_status lcf_sampler_run_rows(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                const int32_t* perm, int32_t store_chain) {
+    if (lcf_status st = lcf_sampler_run_rows_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
     return lcf_sampler_wait(s);
 }
 

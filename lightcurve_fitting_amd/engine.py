@@ -117,6 +117,10 @@ SIGNATURES = [
     ('lcf_sampler_mailbox_connect', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     ('lcf_sampler_run_peers', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sampler_run_peers_async', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_board_export', C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ('lcf_sampler_board_connect', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ('lcf_sampler_run_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
+    ('lcf_sampler_run_rows_async', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_sed_destroy', None, [C.c_void_p]),
     ('lcf_sed_set_observations', C.c_int, [C.c_void_p, C.c_int64, _ip, _ip, _dp, _dp]),
@@ -391,6 +395,28 @@ class NativeSampler:
         hb = C.create_string_buffer(b''.join(handles), 64 * n_ranks) if handles is not None else None
         lp = (C.c_void_p * n_ranks)(*local_ptrs) if local_ptrs is not None else None
         _check(self._lib.lcf_sampler_mailbox_connect(self._h, int(n_ranks), int(rank), hb, lp))
+
+    def board_export(self):
+        """(64-byte IPC handle, local device pointer) of this rank's row board (see ``lcf_sampler_run_rows``)."""
+        h = C.create_string_buffer(64)
+        ptr = C.c_void_p()
+        _check(self._lib.lcf_sampler_board_export(self._h, h, C.byref(ptr)))
+        return h.raw, ptr.value
+
+    def board_connect(self, n_ranks, rank, handles=None, local_ptrs=None):
+        """Map every rank's row board: IPC handles of all ranks, or device pointers of ranks emulated in this process."""
+        hb = C.create_string_buffer(b''.join(handles), 64 * n_ranks) if handles is not None else None
+        lp = (C.c_void_p * n_ranks)(*local_ptrs) if local_ptrs is not None else None
+        _check(self._lib.lcf_sampler_board_connect(self._h, int(n_ranks), int(rank), hb, lp))
+
+    def run_rows(self, first_step, nsteps, split='random', store=True, asynchronous=False):
+        """Collective in effect: the sharded run in which nothing is replicated -- every rank moves its share of the
+        walkers with the one-workgroup-per-proposal kernel and posts their rows on all ranks' boards (see
+        ``lcf_sampler_run_rows``); ``asynchronous``: enqueue only, :meth:`wait` completes it."""
+        mode, keep, pp = self._split(split, nsteps, self.nwalkers)
+        fn = self._lib.lcf_sampler_run_rows_async if asynchronous else self._lib.lcf_sampler_run_rows
+        _check(fn(self._h, int(first_step), int(nsteps), mode, pp, int(bool(store))))
+        self._last = (int(nsteps), bool(store))
 
     def run_peers(self, first_step, nsteps, split='random', store=True, asynchronous=False):
         """Collective in effect: the sharded run over peer mailboxes (see ``lcf_sampler_run_peers``);

@@ -278,8 +278,9 @@ class EnsembleSampler:
         #: behind this switch / LCF_COLLECTIVE=peers until it has been measured on a multi-GPU node)
         import os
         self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'allgather')
-        if self.collective not in ('allgather', 'peers'):
-            raise ValueError("collective must be 'allgather' or 'peers'")
+        if self.collective not in ('allgather', 'peers', 'rows'):
+            raise ValueError("collective must be 'allgather', 'peers' or 'rows'")
+        self._boards = None
         self._peers = None  # True once the mailboxes are connected, False if unavailable
         self._comm = None  # NativeComm once created, False if unavailable
         self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
@@ -354,6 +355,38 @@ class EnsembleSampler:
             self._peers = ok
         return self._peers
 
+    def _peer_boards(self):
+        """Connect the ranks' row boards (once), as :meth:`_peer_mailboxes` connects the mailboxes: for the sharded run
+        in which every rank moves its share of the walkers itself (``lcf_sampler_run_rows``)."""
+        if self._boards is None:
+            import torch
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(self._group), dist.get_rank(self._group)
+            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+
+            def agreed(ok):
+                flag = torch.tensor([1 if ok else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+                return int(flag.item()) == 1
+
+            handle = None
+            try:
+                if world <= 8 and ((self.nwalkers + 1) // 2) % world == 0 and self._native.set_half_step_kernel('auto') == 'solo':
+                    handle, _ = self._native.board_export()
+            except Exception:  # noqa: BLE001 - then every rank falls back to the all-gather
+                handle = None
+            ok = agreed(handle is not None)
+            if ok:
+                handles = [None] * world
+                dist.all_gather_object(handles, handle, group=self._group)
+                try:
+                    self._native.board_connect(world, rank, handles=handles)
+                except Exception:  # noqa: BLE001
+                    ok = False
+                ok = agreed(ok)
+            self._boards = ok
+        return self._boards
+
     def _distributed(self):
         try:
             import torch.distributed as dist
@@ -399,7 +432,11 @@ class EnsembleSampler:
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         self._in_flight = False
         try:
-            if self._distributed() and self.collective == 'peers' and self._peer_mailboxes():
+            if self._distributed() and self.collective == 'rows' and self._peer_boards():
+                import torch.distributed as dist
+                dist.barrier(group=self._group)  # every rank has returned from its previous run (see lcf_sampler_run_rows)
+                self._native.run_rows(self._steps_done, nsteps, split, store)
+            elif self._distributed() and self.collective == 'peers' and self._peer_mailboxes():
                 import torch.distributed as dist
                 dist.barrier(group=self._group)  # every rank has returned from its previous run (see lcf_sampler_run_peers)
                 self._native.run_peers(self._steps_done, nsteps, split, store)

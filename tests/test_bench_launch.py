@@ -49,10 +49,12 @@ def test_two_rank_bench_line_on_one_device(workload):
     assert len(out.stdout.splitlines()) == 1, out.stdout[:500]   # ONE line: what libraries print goes to stderr
     line = json.loads(out.stdout)
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['steps'] == 6
-    # both multi-rank drivers are probed (peer mailboxes over IPC, collectives -- gloo here), the faster one is timed
+    # all multi-rank drivers are probed (row boards and peer mailboxes over IPC, collectives -- gloo here), the fastest
+    # one is timed
     coll = line['collective']
     probe = coll['probe']
-    assert probe['peers']['ok'] and probe['allgather']['ok'] and probe['peers']['replicas_agree']
-    assert probe['selected'] in ('peers', 'allgather') and coll.get('group_ranks', 2) == 2
+    assert all(probe[m]['ok'] and probe[m]['replicas_agree'] for m in ('rows', 'peers', 'allgather'))
+    assert probe['selected'] in ('rows', 'peers', 'allgather') and coll.get('group_ranks', 2) == 2
+    assert ('row boards' in coll['driver']) == (probe['selected'] == 'rows')
     assert ('mailboxes' in coll['driver']) == (probe['selected'] == 'peers')
     assert 0 < line['roofline']['frac'] <= 1

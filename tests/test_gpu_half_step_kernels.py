@@ -187,6 +187,56 @@ def test_peer_mailboxes_emulated_ranks(ranks):
         assert np.array_equal(s.naccepted(), want_acc)
 
 
+@pytest.mark.parametrize('ranks,nwalkers,split', [(2, 48, 'random'), (3, 54, 'random'), (2, 44, 'identity'), (3, 42, 'random')])
+def test_row_boards_emulated_ranks(ranks, nwalkers, split):
+    """The sharded run in which nothing is replicated: every emulated rank moves ITS share of the walkers with k_solo and
+    posts their rows (position, log-posterior, acceptance count) on all boards; state, counts and chain are complete on
+    every rank at the end and equal the single-GPU run bit for bit -- also across two runs that continue each other,
+    with a fixed colouring, and with 21 slots per half-step shared by 3 ranks (42 walkers)."""
+    pb, eng = _multiband()
+    nsteps = 9
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(4).standard_normal((nwalkers, 5)))
+    _, want_chain, want_lp, want_acc, ref = _run(eng, nwalkers, 321, x0, nsteps, 'auto', split)
+    want_x, want_lp_end = ref.get_state()
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    lc = lc_dict(pb['t'], [b.name for b in pb['bands']], pb['y'], pb['dy'])
+    engines = [M.ShockCooling(redshift=0.004).engine_for(lc, priors=priors) for _ in range(ranks)]
+    samplers = [NativeSampler(e, nwalkers, 321) for e in engines]
+    ptrs = [s.board_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.board_connect(ranks, r, local_ptrs=ptrs)
+        s.set_state(x0)                       # (size every buffer first: see the mailbox test above)
+        s.run(100, nsteps, split, True)
+        s.set_state(x0)
+    for first, n in ((0, 4), (4, nsteps - 4)):
+        for s in samplers:
+            s.run_rows(first, n, split, True, asynchronous=True)
+        for s in samplers:
+            s.wait()
+    for s in samplers:
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain[4:]) and np.array_equal(lp, want_lp[4:])
+        assert np.array_equal(s.naccepted(), want_acc)
+        x, lp_end = s.get_state()
+        assert np.array_equal(x, want_x) and np.array_equal(lp_end, want_lp_end)
+
+
+@pytest.mark.parametrize('ranks', [2, 3])
+def test_row_boards_between_processes(ranks):
+    """Real processes, HIP IPC: tools/peer_ranks_check.py with the row boards."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'peer_ranks_check.py'), str(ranks), '48', '10', 'rows'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['every_rank_equals_the_single_gpu_chain'] and line['connected_on_every_rank'] and line['driver'] == 'rows'
+
+
 @pytest.mark.parametrize('ranks', [2, 3])
 def test_peer_mailboxes_between_processes(ranks):
     """Real processes, HIP IPC: tools/peer_ranks_check.py (every rank == the single-GPU chain, mailboxes connected)."""

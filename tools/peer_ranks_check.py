@@ -4,7 +4,9 @@ mailboxes through HIP IPC, stores its shard's rows straight into them and polls 
 with no collective (what xGMI peer writes do on a node; here the peers' memory is the same device).  Every rank must
 end with the chain of the single-GPU run, bit for bit.
 
-    python tools/peer_ranks_check.py [n_ranks=2] [n_walkers=64] [n_steps=12]
+    python tools/peer_ranks_check.py [n_ranks=2] [n_walkers=64] [n_steps=12] [peers|rows]
+
+`rows`: the same check for the row boards (every rank moves its share of the walkers itself and posts their rows).
 
 Started without a launcher it spawns the ranks itself (fresh processes; the parent never touches the GPU); rank 0
 prints one JSON line."""
@@ -22,6 +24,7 @@ def main():
     n_ranks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     n_walkers = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    driver = sys.argv[4] if len(sys.argv) > 4 else 'peers'
     if 'WORLD_SIZE' not in os.environ:
         import bench
         port = bench.free_port()
@@ -53,16 +56,19 @@ def main():
     ref = EnsembleSampler(n_walkers, 5, eng, seed=2024, group=None, collective='allgather')
     ref._distributed = lambda: False          # the single-GPU run of the same ensemble
     ref.run_mcmc(x0, n_steps)
-    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective='peers')
+    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective=driver)
     s.run_mcmc(x0, n_steps // 2)
     s.run_mcmc(None, n_steps - n_steps // 2)   # a second run: generations continue, the barrier between runs
-    same = bool(np.array_equal(s.get_chain(), ref.get_chain()) and np.array_equal(s.get_log_prob(), ref.get_log_prob()))
+    same = bool(np.array_equal(s.get_chain(), ref.get_chain()) and np.array_equal(s.get_log_prob(), ref.get_log_prob()) and
+                np.array_equal(s.acceptance_fraction, ref.acceptance_fraction) and
+                np.array_equal(s._state[0], ref._state[0]))
     flags = [None] * n_ranks
-    dist.all_gather_object(flags, (same, bool(s._peers), float(s.last_run_ms)))
+    dist.all_gather_object(flags, (same, bool(s._boards if driver == 'rows' else s._peers), float(s.last_run_ms)))
     if rank == 0:
         print(json.dumps({'ranks': n_ranks, 'walkers': n_walkers, 'steps': n_steps,
                           'every_rank_equals_the_single_gpu_chain': all(f[0] for f in flags),
-                          'peer_mailboxes_connected_on_every_rank': all(f[1] for f in flags),
+                          'driver': driver, 'connected_on_every_rank': all(f[1] for f in flags),
+                          'peer_mailboxes_connected_on_every_rank': driver == 'peers' and all(f[1] for f in flags),
                           'device_ms_last_run': [f[2] for f in flags],
                           'acceptance': float(s.acceptance_fraction.mean())}), flush=True)
     dist.barrier()
