@@ -483,7 +483,6 @@ struct DevSampler {
     // that moves a walker posts the row on EVERY rank's board; nobody else computes anything about that walker.
     unsigned long long* board;
     unsigned long long* peer_board[kMaxPeers];
-    unsigned int* done_count;   // workgroups of the current launch that have committed (ordinary device memory)
     int n_board_ranks, board_rank;
 };
 
@@ -959,7 +958,8 @@ __device__ unsigned long long g_stamps[64 * 16];
 // One float64 = two 8-byte granules {32 data bits, 32-bit tag}, tag = half-step after which the row holds + 1 (the LL
 // protocol of the mailboxes above); version ring of kRing half-steps.  Safe because (a) a reader asks for exactly the
 // version the draw record names (DrawRec::wage / page) and waits, bounded, until both granules carry its tag; (b) no rank
-// starts half-step G before every rank has finished G - 2 (progress words): half-steps G - 1 and G are the only ones in
+// starts half-step G before every rank has finished G - 2 (progress words, posted by the first workgroup of a rank's
+// NEXT launch: stream order proves that the launch before it is complete): half-steps G - 1 and G are the only ones in
 // flight anywhere, they read versions >= G - 3 and write G and G + 1, so eight versions are never overrun.
 constexpr int kRing = 8;
 constexpr int kBoardTail = kMaxPeers + 1 + 4;   // 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis
@@ -1019,17 +1019,6 @@ __device__ inline double board_take(const DevSampler& sm, unsigned int tag, int 
 __device__ inline unsigned int board_tag(long long G, int age, long long g_run0) {
     const long long t = G - age + 1;
     return (unsigned int)(t < g_run0 ? g_run0 : t);
-}
-
-// A workgroup of this rank's launch of half-step G is through (committed and posted): the last one tells every rank.
-__device__ inline void board_launch_done(const DevSampler& sm, long long G) {
-    const unsigned int before = atomicAdd(sm.done_count, 1u);
-    if (before + 1u == gridDim.x) {
-        atomicExch(sm.done_count, 0u);   // (the next launch is behind this one in the stream)
-        for (int r = 0; r < sm.n_board_ranks; ++r)
-            __hip_atomic_store(board_progress(sm.peer_board[r], sm) + sm.board_rank, (unsigned int)(G + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // Start of a run: this rank's complete state as version `tag` (= the run's first half-step: "the state in front of it")
@@ -1182,10 +1171,12 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     const bool reddened = pb.model == kShockCooling3;
     LCF_STAMP(0, 0);
     const DrawRec dr = draws[i];     // wave-uniform
-    if (dr.wid < 0) {                // an odd ensemble's smaller colour leaves its last slot empty
-        if (BOARD && tid == 0) board_launch_done(sm, G);
-        return;
-    }
+    if (BOARD && blockIdx.x == 0 && tid < sm.n_board_ranks)
+        // This launch runs, so every launch in front of it in the stream has finished: tell every rank that this rank
+        // is through with all half-steps before G (stream order does the counting; no atomics).
+        __hip_atomic_store(board_progress(sm.peer_board[tid], sm) + sm.board_rank, (unsigned int)G, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
     LCF_STAMP(0, 1);
     if (tid < 64) {
         proposal_head<ND, BOARD>(pb, sm, dr, tid, sc, sq, sx, G, g_run0);
@@ -1208,6 +1199,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
             bool abort = false;
             for (;;) {
                 bool ok = true;
+                // rank `lane` has posted P when all its half-steps before P were finished: G - 2 is finished from P = G - 1
                 if (G - 2 >= g_run0 && lane < sm.n_board_ranks)   // (earlier half-steps ended with an earlier run)
                     ok = (int)(__hip_atomic_load(progress + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
                                (unsigned int)(G - 1)) >= 0;
@@ -1286,10 +1278,8 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
             else
                 sm.nacc[dr.wid] = (long long)v;
         }
-        if (tid == 0) {
-            if (nlp != nlp) atomicOr(sm.err, 1);
-            board_launch_done(sm, G);
-        }
+        if (tid == 0 && nlp != nlp) atomicOr(sm.err, 1);
+        LCF_STAMP(0, 10);
         return;
     }
     if (tid != 0) return;
@@ -3118,10 +3108,6 @@ lcf_status board_alloc(lcf_sampler* s) {
     // uncached (fine-grained) device memory: peers' stores over the fabric and this rank's polls meet in memory
     LCF_HIP(hipExtMallocWithFlags(&s->board_mem, s->board_bytes(), hipDeviceMallocUncached));
     LCF_HIP(hipMemset(s->board_mem, 0, s->board_bytes()));  // tag 0: no version (half-steps are numbered from 2)
-    if (!s->ds.done_count) {
-        if (lcf_status st = dalloc(&s->ds.done_count, 1, s->owned)) return st;
-        LCF_HIP(hipMemset(s->ds.done_count, 0, sizeof(unsigned int)));
-    }
     s->ds.board = static_cast<unsigned long long*>(s->board_mem);
     return LCF_OK;
 }

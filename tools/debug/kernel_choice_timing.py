@@ -37,3 +37,16 @@ for a in names:
     for b in names:
         if a < b:
             print(f'{a} == {b}:', np.array_equal(chains[a][0], chains[b][0]) and np.array_equal(chains[a][1], chains[b][1]))
+
+# the row-board form of k_solo with ONE rank: what reading rows from tagged words in uncached memory and posting them costs
+s = NativeSampler(eng, nw, 11)
+ptr = s.board_export()[1]
+s.board_connect(1, 0, local_ptrs=[ptr])
+s.set_state(x0)
+s.run_rows(0, 50, 'random', False)
+t0 = time.perf_counter()
+s.run_rows(50, steps, 'random', False)
+wall = time.perf_counter() - t0
+x, lp = s.get_state()
+print(f'rows   -> k_solo over its own board: {nw * steps / wall:.3e} walker-steps/s wall, device {1e3 * s.last_run_ms() / (2 * steps):.2f} us '
+      f'per half-step; same state as solo: {np.array_equal(x, chains["solo"][0])}')
