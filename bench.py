@@ -472,6 +472,10 @@ def run_mcmc(args):
     scaling = args.scaling or 'weak'
     n_walkers = WALKERS_PER_GPU * (world if scaling == 'weak' else 1)
     x0 = initial_walkers(n_walkers)
+    # The dominant kernel alone (HIP events over 2000 back-to-back launches), at this rank's share of a half-step when
+    # the run is sharded.  Measured BEFORE the timed steps: a device that has just been handed over idles at low clocks,
+    # and a 20-step run (0.6 ms) would be over before they have ramped (the driver's default is that short).
+    kern_ms, used = half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7) if rank == 0 or world > 1 else (None, None)
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=mode), dist,
                                      x0, args)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
@@ -482,7 +486,6 @@ def run_mcmc(args):
     if rank == 0:
         # dominant kernel alone, at this rank's share of a half-step when the run is sharded over the GPUs
         per_rank = n_walkers // world
-        kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7)
         quads, n_interp = quads_per_evaluation(engine, TRUTH)
         name = {'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
                         '+ likelihood + accept test)',
@@ -572,6 +575,7 @@ def run_companion(args):
     engine = model.engine_for(lc, priors=priors)
     engine._variant = 3
     x0 = companion_walkers(nw)
+    kern_ms, used = half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=200) if rank == 0 or world > 1 else (None, None)
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(nw, 8, engine, seed=SEED, collective=mode), dist, x0,
                                      args)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
@@ -581,7 +585,6 @@ def run_companion(args):
         coll['probe'] = probe
     if rank == 0:
         per_rank = nw // world
-        kern_ms, used = half_step_kernel_ms(engine, per_rank, x0, SEED + 7, reps=200)
         quads, n_interp = quads_per_evaluation(engine, COMPANION_TRUTH)
         full = int(engine.samples_per_eval)
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point

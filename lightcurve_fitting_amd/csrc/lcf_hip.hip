@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +40,9 @@
 #endif
 #ifndef LCF_KPRE_SOLO
 #define LCF_KPRE_SOLO 2  // the same in the one-workgroup-per-proposal kernel (4: 3.73e7 walker-steps/s, 3: 3.74e7, 2: 3.78e7)
+#endif
+#ifndef LCF_FIRST_BLOCK
+#define LCF_FIRST_BLOCK 32  // steps in the first block of draw records of a run (the later ones: up to 256)
 #endif
 #ifndef LCF_WAVES
 #define LCF_WAVES 4  // occupancy the register allocator is asked to keep (waves per SIMD)
@@ -2205,6 +2209,7 @@ struct lcf_sampler {
     size_t snap_acc() const { return snap_lp() + (size_t)ds.n_walkers * sizeof(double); }
     size_t snap_bytes() const { return snap_acc() + (size_t)ds.n_walkers * sizeof(long long); }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_snap = nullptr;   // behind the snapshot kernel: what a caller of a finished run waits for
     double last_ms = 0.;
 
     ~lcf_sampler() {
@@ -2221,6 +2226,7 @@ struct lcf_sampler {
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
+        if (ev_snap) hipEventDestroy(ev_snap);
     }
     void free_blocks() {
         for (int b = 0; b < 2; ++b) {
@@ -2578,6 +2584,7 @@ lcf_status enqueue_snapshot(lcf_sampler* s) {
     hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ds,
                        reinterpret_cast<unsigned long long*>(s->snap));
     LCF_HIP(hipGetLastError());
+    LCF_HIP(hipEventRecord(s->ev_snap, st));
     s->snap_enqueued = true;
     s->snap_valid = false;
     return LCF_OK;
@@ -2589,7 +2596,17 @@ lcf_status settle(lcf_sampler* s) {
     if (s->snap_valid && !s->pending && !s->foreign_stream) return LCF_OK;
     if (!s->snap_enqueued || s->pending || s->foreign_stream)
         if (lcf_status r = enqueue_snapshot(s)) return r;
-    LCF_HIP(hipStreamSynchronize(s->e->stream));
+    // Wait for the snapshot, not for the stream: what a run enqueues behind it (the draw records of a possible
+    // continuation, 30-40 us of kernels) is nobody's business here -- everything later on the stream is ordered behind
+    // it anyway.  A short run ends within a millisecond of this call: poll for that long before handing the wait to
+    // the driver.
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipEventQuery(s->ev_snap) == hipErrorNotReady &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) {
+        }
+    }
+    LCF_HIP(hipEventSynchronize(s->ev_snap));
     s->snap_enqueued = false;
     s->snap_valid = true;
     return LCF_OK;
@@ -2685,7 +2702,7 @@ lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, in
             LCF_HIP(hipFuncSetAttribute((const void*)k_make_perm, hipFuncAttributeMaxDynamicSharedMemorySize, n_pad * 8));
     }
     s->blk_steps = s->blk_cap;
-    s->blk_first = std::min<int64_t>(s->blk_cap, 8);
+    s->blk_first = std::min<int64_t>(s->blk_cap, LCF_FIRST_BLOCK);
     if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown) {
         s->spec_first = -1;  // the previous run left this run's first block behind (speculate_continuation)
         s->blk_generated = 0;
@@ -2729,6 +2746,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
     LCF_HIP(hipEventCreate(&s->ev0));
     LCF_HIP(hipEventCreate(&s->ev1));
+    LCF_HIP(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
     LCF_HIP(hipHostMalloc((void**)&s->snap, s->snap_bytes(), hipHostMallocDefault));
     *out = s;
     return LCF_OK;
