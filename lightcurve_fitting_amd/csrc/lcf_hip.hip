@@ -55,6 +55,14 @@ using namespace lcf;
 // =================================================================================================================
 namespace {
 
+// The value lane `lane` (wave-uniform) holds, in every lane: two v_readlane instead of the LDS round trip of a shuffle
+// (the serial heads wait for ~20 of them with nothing else to issue).
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -741,11 +749,11 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
         for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
 #pragma unroll
         for (int d = 0; d < kD; ++d) {
-            const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
+            const double xi = lane_value(row[d], 1), cj = lane_value(row[d], 2);
             q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
             if (lane == d && d < pb.n_par) arg = q[d];
         }
-        const double lp_i = __shfl(lp_cur, 1, 64);
+        const double lp_i = lane_value(lp_cur, 1);
         if (!mine) {
             // another rank evaluates this proposal: only what later accept tests need is published here
             // (its log-prior reaches this rank inside the gathered log-posterior)
@@ -759,7 +767,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
         }
         const double lg = flog(arg);  // one logarithm per lane, all at once
 #pragma unroll
-        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
+        for (int d = 0; d < kD; ++d) lq[d] = lane_value(lg, d);
         double c[kNCoef];
         walker_coefficients(pb, q, lq, c, pb.use_itab != 0 && pb.variant != 0);
         // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
@@ -772,7 +780,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
             const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
 #pragma unroll
             for (int d = 0; d < kD; ++d)
-                if (d < nd) lpr += __shfl(mine, d, 64);
+                if (d < nd) lpr += lane_value(mine, d);
         }
         if (lane == 0) {
             for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
@@ -1088,12 +1096,12 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
         if (own ? col <= nd + 1 : col < nd)
             got = board_take(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
     }
-    const double lp_i = BOARD ? __shfl(got, 16 + nd, 64) : sm.LP[dr.wid];
+    const double lp_i = BOARD ? lane_value(got, 16 + nd) : sm.LP[dr.wid];
     double arg = 1.;
 #pragma unroll
     for (int d = 0; d < kD; ++d) {
-        x[d] = d < nd ? (BOARD ? __shfl(got, 16 + d, 64) : xs[d]) : 0.;
-        const double cj = d < nd ? (BOARD ? __shfl(got, d, 64) : cs_[d]) : 0.;
+        x[d] = d < nd ? (BOARD ? lane_value(got, 16 + d) : xs[d]) : 0.;
+        const double cj = d < nd ? (BOARD ? lane_value(got, d) : cs_[d]) : 0.;
         q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
         if (lane == d && d < pb.n_par) arg = q[d];
     }
@@ -1103,7 +1111,7 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
     LCF_STAMP(0, 2);
     const double lg = flog(arg);
 #pragma unroll
-    for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
+    for (int d = 0; d < kD; ++d) lq[d] = lane_value(lg, d);
     LCF_STAMP(0, 3);
     double c[kNCoef];
     walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
@@ -1117,9 +1125,9 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
         const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;
 #pragma unroll
         for (int d = 0; d < kD; ++d)
-            if (d < nd) lpr += __shfl(mine, d, 64);   // the same ordered sum as walker_log_prior
+            if (d < nd) lpr += lane_value(mine, d);   // the same ordered sum as walker_log_prior
     }
-    const double count = BOARD ? __shfl(got, 16 + nd + 1, 64) : 0.;
+    const double count = BOARD ? lane_value(got, 16 + nd + 1) : 0.;
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];

@@ -287,3 +287,40 @@ def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
         assert all(np.array_equal(u, v) for u, v in zip(a, b))
     ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pbs[2]), x0[2], 9, 17 + 2)
     assert relerr(chains[False][2][0], ref) < 1e-9 and relerr(chains[False][2][1], ref_lp) < 1e-9
+
+
+def test_row_boards_companion_shape():
+    """The row boards with the companion model of configs[2]: 8 parameters, 8000 points in four parts, 1024-thread
+    workgroups (k_solo<8, 1, true, 4, BOARD>); two emulated ranks, 40 walkers, equal to the single-GPU run bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    model, lc, priors, _ = bench.build_companion(0)
+    nwalkers, nsteps = 40, 4
+    x0 = bench.companion_walkers(nwalkers)
+    ref = NativeSampler(model.engine_for(lc, priors=priors), nwalkers, 9)
+    assert ref.set_half_step_kernel('auto') == 'solo'
+    ref.set_state(x0)
+    ref.run(0, nsteps, 'random', True)
+    want_chain, want_lp = ref.get_chain()
+    engines = [type(model)(model._sn_lc, redshift=0.003).engine_for(lc, priors=priors) if hasattr(model, '_sn_lc') else None
+               for _ in range(2)]
+    if engines[0] is None:      # (the model keeps one engine per light curve: make two models for two engines)
+        engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
+    assert engines[0] is not engines[1]
+    samplers = [NativeSampler(e, nwalkers, 9) for e in engines]
+    ptrs = [s.board_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.board_connect(2, r, local_ptrs=ptrs)
+        s.set_state(x0)
+        s.run(100, nsteps, 'random', True)
+        s.set_state(x0)
+    for s in samplers:
+        s.run_rows(0, nsteps, 'random', True, asynchronous=True)
+    for s in samplers:
+        s.wait()
+    for s in samplers:
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
+        assert np.array_equal(s.naccepted(), ref.naccepted())
