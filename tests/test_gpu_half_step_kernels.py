@@ -304,10 +304,8 @@ def test_row_boards_companion_shape():
     ref.set_state(x0)
     ref.run(0, nsteps, 'random', True)
     want_chain, want_lp = ref.get_chain()
-    engines = [type(model)(model._sn_lc, redshift=0.003).engine_for(lc, priors=priors) if hasattr(model, '_sn_lc') else None
-               for _ in range(2)]
-    if engines[0] is None:      # (the model keeps one engine per light curve: make two models for two engines)
-        engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
+    # (a model keeps one engine per light curve: two models for the two ranks' engines)
+    engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
     assert engines[0] is not engines[1]
     samplers = [NativeSampler(e, nwalkers, 9) for e in engines]
     ptrs = [s.board_export()[1] for s in samplers]
