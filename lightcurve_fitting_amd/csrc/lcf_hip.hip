@@ -56,7 +56,8 @@ using namespace lcf;
 namespace {
 
 // The value lane `lane` (wave-uniform) holds, in every lane: two v_readlane instead of the LDS round trip of a shuffle
-// (the serial heads wait for ~20 of them with nothing else to issue).
+// (the serial heads wait for ~20 of them with nothing else to issue).  Used by the one-workgroup-per-proposal heads; in
+// k_fused's step_serial the extra scalar registers tip two instantiations into scratch, so it keeps the shuffles.
 __device__ __forceinline__ double lane_value(double v, int lane) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
@@ -749,11 +750,11 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
         for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
 #pragma unroll
         for (int d = 0; d < kD; ++d) {
-            const double xi = lane_value(row[d], 1), cj = lane_value(row[d], 2);
+            const double xi = __shfl(row[d], 1, 64), cj = __shfl(row[d], 2, 64);
             q[d] = d < nd ? cj - (cj - xi) * dr.z : 0.;
             if (lane == d && d < pb.n_par) arg = q[d];
         }
-        const double lp_i = lane_value(lp_cur, 1);
+        const double lp_i = __shfl(lp_cur, 1, 64);
         if (!mine) {
             // another rank evaluates this proposal: only what later accept tests need is published here
             // (its log-prior reaches this rank inside the gathered log-posterior)
@@ -767,7 +768,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
         }
         const double lg = flog(arg);  // one logarithm per lane, all at once
 #pragma unroll
-        for (int d = 0; d < kD; ++d) lq[d] = lane_value(lg, d);
+        for (int d = 0; d < kD; ++d) lq[d] = __shfl(lg, d, 64);
         double c[kNCoef];
         walker_coefficients(pb, q, lq, c, pb.use_itab != 0 && pb.variant != 0);
         // log-prior: lane d evaluates parameter d with its descriptor fetched at kernel entry, then an ordered sum
@@ -780,7 +781,7 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
             const double mine = lane < pb.n_dim ? prior_term(my_prior, qv) : 0.;  // one evaluation per lane
 #pragma unroll
             for (int d = 0; d < kD; ++d)
-                if (d < nd) lpr += lane_value(mine, d);
+                if (d < nd) lpr += __shfl(mine, d, 64);
         }
         if (lane == 0) {
             for (int k = 0; k < kNCoef; ++k) sc[k] = c[k];
@@ -3210,9 +3211,9 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
     const unsigned collect_blocks = (unsigned)((ds.n_half + 3) / 4);
     for (int64_t k = 0; k < 2 * n_steps; ++k) {
         if (lcf_status r = launch_solo(s, k, st, true, lo, hi)) return r;
-        if (store_chain) {  // the rows of this half-step, from every rank, into the chain
-            hipLaunchKernelGGL(k_board_collect, dim3(collect_blocks), dim3(256), 0, st, ds, (long long)(s->g_run0 + k),
-                               (long long)(k / 2), s->rows(k), 1, 0, 1);
+        if (store_chain && (k & 1)) {  // the rows of this step's two half-steps, from every rank, into the chain
+            hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds,
+                               (long long)(s->g_run0 + k - 1), (long long)(k / 2), s->rows(k - 1), 2, 0, 1);
             LCF_HIP(hipGetLastError());
         }
     }
