@@ -186,12 +186,19 @@ def timed_run(sampler, dist, warmup, steps, x0):
             dist.barrier()
             torch.cuda.synchronize()
 
+    import gc
     sampler.run_mcmc(x0, warmup, store=False)         # untimed warm-up (also allocates everything)
-    barrier()
-    t0 = time.perf_counter()
-    sampler.run_mcmc(None, steps, store=False)        # returns after the device has finished
-    barrier()
-    return max_over_ranks(dist, time.perf_counter() - t0)
+    gc.collect()
+    gc.disable()     # (as timeit does: a generation-2 collection of the interpreter, 77 ms when it strikes, is not the
+    try:             # sampler's time; seen once in eight 0.6 ms runs, tools/debug/short_run_breakdown.py)
+        barrier()
+        t0 = time.perf_counter()
+        sampler.run_mcmc(None, steps, store=False)    # returns after the device has finished
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    return max_over_ranks(dist, elapsed)
 
 
 def pick_collective(make_sampler, dist, x0, args):
