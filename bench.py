@@ -595,10 +595,10 @@ def run_companion(args):
         quads, n_interp = quads_per_evaluation(engine, COMPANION_TRUTH)
         full = int(engine.samples_per_eval)
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
-        name = {'solo': 'k_solo<8,1,true,4> (one 1024-thread workgroup per proposal)', 'fused': 'k_fused<8,1,true>',
+        name = {'solo': 'k_solo<8,1,true,4> (one 512-thread workgroup per proposal, its two halves take two of the four parts each)', 'fused': 'k_fused<8,1,true>',
                 'phases': 'k_step + k_points'}[used]
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr,
-                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 16,
+                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 8,
                               interp=(n_interp, 1000) if n_interp else None)
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,

@@ -1161,8 +1161,12 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // BOARD (multi-GPU, lcf_sampler_run_rows): the launch covers this rank's slots [slot_lo, slot_lo + gridDim.x) of
 // half-step G; rows come from this rank's row board and the commit posts the walker's new row on EVERY rank's board.
 // No rank computes anything about another rank's proposals, and nothing but these rows travels.
+// NPARTS: 2 = engines with up to two parts, one per 256 threads; 4 = three or four parts, the two groups of 256
+// threads take parts j, j + 2 one after the other.  512 threads either way, so that two workgroups share a CU and one's
+// serial head overlaps the other's points (1024-thread workgroups for four parts, one per CU: companion fit 1.26e7
+// walker-steps/s; this way 1.41e7).
 template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false>
-__global__ __launch_bounds__(kBlock * NPARTS, LCF_WAVES)
+__global__ __launch_bounds__(kBlock * 2, LCF_WAVES)
 void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
             const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1177,7 +1181,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
     int* sctl = reinterpret_cast<int*>(sc + kSoloScratch + 2);              // BOARD: [0] = 1: the launch is aborted
     double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
-    constexpr int kThreads = kBlock * NPARTS;
+    constexpr int kThreads = kBlock * 2;
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const int tid = threadIdx.x, i = blockIdx.x + (BOARD ? slot_lo : 0);
@@ -1242,6 +1246,7 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
         const int part = tid / kBlock, ltid = tid % kBlock;
         if (THERM) {
             // thread (part, ltid) computes the epochs a k_fused workgroup of that part would: same values, all in LDS
+            // (NPARTS = 4: of parts `part` and `part + 2`)
             const int e0 = part_entry(pb.part_ep0, part), e1 = part_entry(pb.part_ep0, part + 1);
 #pragma unroll 1
             for (int e = e0 + ltid; e < e1; e += kBlock) {
@@ -1252,16 +1257,38 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
                     thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
                 lth[e] = make_double2(invT, pref);
             }
+            if (NPARTS > 2) {
+                const int f0 = part_entry(pb.part_ep0, part + 2), f1 = part + 2 < pb.n_parts ? part_entry(pb.part_ep0, part + 3) : f0;
+#pragma unroll 1
+                for (int e = f0 + ltid; e < f1; e += kBlock) {
+                    double T, invT, pref;
+                    if (pb.use_itab)
+                        thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
+                    else
+                        thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
+                    lth[e] = make_double2(invT, pref);
+                }
+            }
         }
         if (THERM || reddened) __syncthreads();
         LCF_STAMP(0, 7);
-        if (part < pb.n_parts)
-            term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
-                                                           nullptr, nullptr, ltid, itab_at);
-        LCF_STAMP(0, 8);
-        LCF_STAMP(1, 12);
-        const double ws = wave_sum(term);
-        if ((tid & 63) == 0) red[tid >> 6] = ws;
+        if (NPARTS > 2) {
+#pragma unroll 1
+            for (int pp = part; pp < pb.n_parts; pp += 2) {
+                term = points_loop<VARIANT, 0, true, THERM, 1>(pb, pp, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
+                                                               nullptr, nullptr, ltid, itab_at);
+                const double ws = wave_sum(term);
+                if ((tid & 63) == 0) red[4 * pp + (ltid >> 6)] = ws;
+            }
+        } else {
+            if (part < pb.n_parts)
+                term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
+                                                               nullptr, nullptr, ltid, itab_at);
+            LCF_STAMP(0, 8);
+            LCF_STAMP(1, 12);
+            const double ws = wave_sum(term);
+            if ((tid & 63) == 0) red[tid >> 6] = ws;
+        }
     }
     __syncthreads();
     LCF_STAMP(0, 9);
@@ -2514,14 +2541,14 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
                 raised = true;                                                                                        \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B>), grid, dim3(kBlock * NP), lds, st, e->dp, ds, row, draws,        \
+        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B>), grid, dim3(kBlock * 2), lds, st, e->dp, ds, row, draws,         \
                            draws_next, G, g_run0, lo);                                                                \
     } while (0)
 #define LCF_SOLO4(ND, V, T, NP)                                                                                       \
     do {                                                                                                              \
         if (board) LCF_SOLO5(ND, V, T, NP, true); else LCF_SOLO5(ND, V, T, NP, false);                                \
     } while (0)
-    // workgroups of 512 threads (up to two parts) or 1024 (three or four)
+    // workgroups of 512 threads: one part per 256 threads (up to two parts) or two (three or four)
 #define LCF_SOLO3(ND, V, T)                                                                                           \
     do {                                                                                                              \
         if (e->dp.n_parts <= 2) LCF_SOLO4(ND, V, T, 2); else LCF_SOLO4(ND, V, T, 4);                                  \
