@@ -322,3 +322,30 @@ def test_row_boards_companion_shape():
         chain, lp = s.get_chain()
         assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
         assert np.array_equal(s.naccepted(), ref.naccepted())
+
+
+def test_row_boards_missing_rank_ends_with_an_error():
+    """A rank that never runs: the waits of the other one are bounded (0.5 s), the run ends with LCF_ERR_STATE and says
+    which row was missing -- it does not hang the device."""
+    import time
+    from lightcurve_fitting_amd.engine import LcfError
+    pb, eng = _multiband()
+    nwalkers = 48
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(4).standard_normal((nwalkers, 5)))
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    lc = lc_dict(pb['t'], [b.name for b in pb['bands']], pb['y'], pb['dy'])
+    engines = [M.ShockCooling(redshift=0.004).engine_for(lc, priors=priors) for _ in range(2)]
+    samplers = [NativeSampler(e, nwalkers, 321) for e in engines]
+    ptrs = [s.board_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.board_connect(2, r, local_ptrs=ptrs)
+        s.set_state(x0)
+    t0 = time.perf_counter()
+    with pytest.raises(LcfError) as err:
+        samplers[0].run_rows(0, 6, 'random', True)     # rank 1 never starts
+    assert time.perf_counter() - t0 < 5.
+    assert err.value.status == 7 and 'was not posted within 0.5 s' in str(err.value)
+    # the sampler is usable again after a new set_state
+    samplers[0].set_state(x0)
+    samplers[0].run(0, 3, 'random', True)
+    assert np.all(np.isfinite(samplers[0].get_chain()[0]))
