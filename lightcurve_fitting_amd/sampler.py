@@ -371,7 +371,8 @@ class EnsembleSampler:
 
             handle = None
             try:
-                if world <= 8 and ((self.nwalkers + 1) // 2) % world == 0 and self._native.set_half_step_kernel('auto') == 'solo':
+                # (whether the engine can run one workgroup per proposal is checked by board_connect on every rank)
+                if world <= 8 and ((self.nwalkers + 1) // 2) % world == 0:
                     handle, _ = self._native.board_export()
             except Exception:  # noqa: BLE001 - then every rank falls back to the all-gather
                 handle = None
