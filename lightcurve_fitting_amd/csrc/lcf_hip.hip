@@ -1951,14 +1951,21 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     if (dp.redden_slow) dp.n_lds_tab = 0;
     dp.tab_in_lds = dp.n_lds_tab > 0;
     dp.n_epochs = (int)epochs.size();
-    dp.use_therm = all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
+    // Thermal states per (walker, epoch), ahead of the point loop.  With >= 2 points per distinct time that is sharing;
+    // without any (real multi-band photometry: every observation has its own time) it still is what puts a light curve
+    // on the fast path -- log-space states in LDS, interpolated band sums, k_solo: 27.8 -> 20.0 us per half-step at the
+    // configs[1] size (tools/debug/ragged_times.py).  LCF_SHARED_EPOCHS_ONLY=1 restores the round-1 rule, sharing or
+    // nothing (read at every engine creation: the tests of the state-inside-the-point-loop kernels set it).
+    const bool shared_only = std::getenv("LCF_SHARED_EPOCHS_ONLY") != nullptr;
+    const bool epochs_ahead = all_finite_t && N > 0 && (!shared_only || 2 * (long long)epochs.size() <= N);
+    dp.use_therm = epochs_ahead;
     dp.variant = 1;
     dp.use_ctab = have_ctab ? 1 : 0;
     e->have_ctab = have_ctab;
     // third level: interpolants of ln S(ln T), staged in LDS behind the descriptors when they take <= 40 KiB
     // (six to ten filters), else read from global memory (L2)
     // (engines whose points share no epochs keep the thermal state inside the point loop, in linear space)
-    const bool have_itab_here = have_itab && all_finite_t && N > 0 && 2 * (long long)epochs.size() <= N;
+    const bool have_itab_here = have_itab && epochs_ahead;
     e->have_itab = have_itab_here;
     dp.use_itab = have_itab_here ? 1 : 0;
     dp.itab_m = have_itab ? pr->itab_m : 0;
@@ -2193,6 +2200,7 @@ extern "C" lcf_status lcf_profile_loglike_kernel(lcf_engine* e, int64_t n, const
 // =================================================================================================================
 struct lcf_sampler {
     lcf_engine* e = nullptr;
+    int device = 0;           // e->device, kept for the destructor
     DevSampler ds{};
     std::vector<void*> owned;
     double *coef = nullptr, *lprior = nullptr;
@@ -2249,7 +2257,8 @@ struct lcf_sampler {
     double last_ms = 0.;
 
     ~lcf_sampler() {
-        hipSetDevice(e->device);
+        // (the device is remembered here: a garbage collector may destroy the engine first, and nothing below needs it)
+        hipSetDevice(device);
         for (void* p : owned) hipFree(p);
         if (ds.chain) hipFree(ds.chain);
         if (ds.chain_lp) hipFree(ds.chain_lp);
@@ -2760,6 +2769,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     LCF_HIP(hipSetDevice(e->device));
     auto* s = new lcf_sampler();
     s->e = e;
+    s->device = e->device;
     DevSampler& ds = s->ds;
     ds.n_walkers = n_walkers;
     ds.n_half = (n_walkers + 1) / 2;  // slots per half-step: the larger colour of an odd ensemble

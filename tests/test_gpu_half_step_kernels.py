@@ -349,3 +349,22 @@ def test_row_boards_missing_rank_ends_with_an_error():
     samplers[0].set_state(x0)
     samplers[0].run(0, 3, 'random', True)
     assert np.all(np.isfinite(samplers[0].get_chain()[0]))
+
+
+@pytest.mark.parametrize('shared_only', [False, True])
+def test_light_curve_without_shared_epochs(shared_only, monkeypatch):
+    """Real multi-band photometry has no two observations at one time.  By default such a light curve still gets its
+    thermal states ahead of the point loop (one "epoch" per point) and with them the fast path -- k_solo, log-space
+    states, interpolated band sums; with LCF_SHARED_EPOCHS_ONLY=1 (the round-1 rule) the state is computed inside the
+    point loop (k_fused, sample tables).  Both are the oracle-driven chain."""
+    if shared_only:
+        monkeypatch.setenv('LCF_SHARED_EPOCHS_ONLY', '1')
+    pb, eng, x0 = _small(26, seed=12)
+    assert len(np.unique(pb['t'])) == len(pb['t'])
+    runs = {k: _run(eng, 26, 77, x0, 6, k) for k in ('auto', 'fused', 'phases')}
+    assert runs['auto'][0] == ('fused' if shared_only else 'solo')
+    for k in ('fused', 'phases'):
+        assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][3], runs[k][3])
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 77)
+    assert relerr(runs['auto'][1], ref) < 1e-9 and relerr(runs['auto'][2], ref_lp) < 1e-9
+    assert np.array_equal(runs['auto'][3], ref_acc)
