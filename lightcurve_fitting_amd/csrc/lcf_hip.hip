@@ -1957,7 +1957,10 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     // configs[1] size (tools/debug/ragged_times.py).  LCF_SHARED_EPOCHS_ONLY=1 restores the round-1 rule, sharing or
     // nothing (read at every engine creation: the tests of the state-inside-the-point-loop kernels set it).
     const bool shared_only = std::getenv("LCF_SHARED_EPOCHS_ONLY") != nullptr;
-    const bool epochs_ahead = all_finite_t && N > 0 && (!shared_only || 2 * (long long)epochs.size() <= N);
+    // (without sharing only while a proposal's states fit beside the tables in LDS, 64 KiB = 4096 observations: beyond
+    // that the states would travel through memory, n_walkers x N x 16 bytes, for nothing)
+    const bool sharing = 2 * (long long)epochs.size() <= N;
+    const bool epochs_ahead = all_finite_t && N > 0 && (sharing || (!shared_only && epochs.size() <= 4096));
     dp.use_therm = epochs_ahead;
     dp.variant = 1;
     dp.use_ctab = have_ctab ? 1 : 0;
