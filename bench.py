@@ -187,10 +187,10 @@ def timed_run(sampler, dist, warmup, steps, x0):
             torch.cuda.synchronize()
 
     import gc
-    sampler.run_mcmc(x0, warmup, store=False)         # untimed warm-up (also allocates everything)
-    gc.collect()
-    gc.disable()     # (as timeit does: a generation-2 collection of the interpreter, 77 ms when it strikes, is not the
-    try:             # sampler's time; seen once in eight 0.6 ms runs, tools/debug/short_run_breakdown.py)
+    gc.collect()     # As timeit does: a generation-2 collection of the interpreter (40-80 ms when it strikes, seen once in
+    gc.disable()     # eight 0.6 ms runs, tools/debug/short_run_breakdown.py) is not the sampler's time.  Collected BEFORE
+    try:             # the warm-up, so that the timed steps follow it without a pause in which the device falls asleep.
+        sampler.run_mcmc(x0, warmup, store=False)     # untimed warm-up (also allocates everything)
         barrier()
         t0 = time.perf_counter()
         sampler.run_mcmc(None, steps, store=False)    # returns after the device has finished

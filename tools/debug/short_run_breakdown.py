@@ -1,4 +1,4 @@
-"""Where the wall time of a 20-step run goes: Python around the native call, the native call, the device."""
+"""Where the wall time of a 20-step run goes: Python around the native calls, the native calls, the device."""
 import os, sys, time
 import numpy as np
 import torch
@@ -12,19 +12,21 @@ bench.half_step_kernel_ms(eng, 1024, x0, 3)
 s = EnsembleSampler(1024, 5, eng, seed=1)
 s.run_mcmc(x0, 5, store=False)
 nat = s._native
-orig = nat.run
 spent = {}
-def timed(*a, **k):
-    t = time.perf_counter(); r = orig(*a, **k); spent['native'] = time.perf_counter() - t; return r
-nat.run = timed
-rows = []
+def wrap(name):
+    orig = getattr(nat, name)
+    def timed(*a, **k):
+        t = time.perf_counter(); r = orig(*a, **k); spent[name] = spent.get(name, 0.) + time.perf_counter() - t; return r
+    setattr(nat, name, timed)
+for name in ('run', 'naccepted', 'get_state'):
+    wrap(name)
 for i in range(8):
+    spent.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     s.run_mcmc(None, 20, store=False)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    rows.append((1e6 * (t2 - t0), 1e6 * (t1 - t0), 1e6 * spent['native'], 1e3 * s.last_run_ms))
-for r in rows:
-    print('wall %.0f us | run_mcmc %.0f | native call %.0f | device (events around the 40 launches) %.0f' % r)
+    print('wall %.0f us | run_mcmc %.0f | native run %.0f, naccepted %.0f, get_state %.0f | device %.0f' %
+          (1e6 * (t2 - t0), 1e6 * (t1 - t0), 1e6 * spent['run'], 1e6 * spent['naccepted'], 1e6 * spent['get_state'], 1e3 * s.last_run_ms))
