@@ -187,9 +187,11 @@ def timed_run(sampler, dist, warmup, steps, x0):
             torch.cuda.synchronize()
 
     import gc
-    gc.collect()     # As timeit does: a generation-2 collection of the interpreter (40-80 ms when it strikes, seen once in
-    gc.disable()     # eight 0.6 ms runs, tools/debug/short_run_breakdown.py) is not the sampler's time.  Collected BEFORE
-    try:             # the warm-up, so that the timed steps follow it without a pause in which the device falls asleep.
+    was_enabled = gc.isenabled()
+    if was_enabled:      # As timeit does: a generation-2 collection of the interpreter (40-80 ms when it strikes, seen
+        gc.collect()     # once in eight 0.6 ms runs, tools/debug/short_run_breakdown.py) is not the sampler's time.
+        gc.disable()     # Collected BEFORE the warm-up (the caller may have done it even earlier, see quiet_interpreter):
+    try:                 # the timed steps must follow busy work without a pause in which the device clocks down.
         sampler.run_mcmc(x0, warmup, store=False)     # untimed warm-up (also allocates everything)
         barrier()
         t0 = time.perf_counter()
@@ -197,8 +199,19 @@ def timed_run(sampler, dist, warmup, steps, x0):
         barrier()
         elapsed = time.perf_counter() - t0
     finally:
-        gc.enable()
+        if was_enabled:
+            gc.enable()
     return max_over_ranks(dist, elapsed)
+
+
+def quiet_interpreter():
+    """Collect the interpreter's garbage now and switch its collector off until the line is printed: the 50 ms a
+    collection takes would otherwise fall between the device's busy phases (kernel timing -> warm-up -> timed steps) and
+    let it clock down -- launches then take 13.2 instead of 12.5 us for the next milliseconds (rocprofv3 trace of a
+    20-step run, tools/debug/trace_short_run.py)."""
+    import gc
+    gc.collect()
+    gc.disable()
 
 
 def pick_collective(make_sampler, dist, x0, args):
@@ -482,9 +495,10 @@ def run_mcmc(args):
     # The dominant kernel alone (HIP events over 2000 back-to-back launches), at this rank's share of a half-step when
     # the run is sharded.  Measured BEFORE the timed steps: a device that has just been handed over idles at low clocks,
     # and a 20-step run (0.6 ms) would be over before they have ramped (the driver's default is that short).
-    kern_ms, used = half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7) if rank == 0 or world > 1 else (None, None)
+    quiet_interpreter()
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=mode), dist,
                                      x0, args)
+    kern_ms, used = half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7) if rank == 0 or world > 1 else (None, None)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = n_walkers * args.steps / elapsed
     coll = collective_info(sampler, dist, world)
@@ -582,9 +596,10 @@ def run_companion(args):
     engine = model.engine_for(lc, priors=priors)
     engine._variant = 3
     x0 = companion_walkers(nw)
-    kern_ms, used = half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=200) if rank == 0 or world > 1 else (None, None)
+    quiet_interpreter()
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(nw, 8, engine, seed=SEED, collective=mode), dist, x0,
                                      args)
+    kern_ms, used = half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=200) if rank == 0 or world > 1 else (None, None)
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = nw * args.steps / elapsed
     coll = collective_info(sampler, dist, world)
