@@ -535,14 +535,16 @@ __device__ inline void thermal_state(const DevProblem& pb, const double* __restr
 //                      linear-space state, for the sample-table band sum.
 // Power-law models never leave log space: ln T = c[6] + eT ln t and ln R_bb^2 = c[7] + eL ln t - E - 4 ln T come from
 // ONE logarithm and at most one exponential per epoch.  The special cases follow thermal_state rule for rule.
-// Logarithm / exponential of the per-epoch state: libm.  Measured at 1024 walkers x 3000 points (walker-steps/s):
-// libm + libm 3.73e7, libm log + table exponential 3.67e7, flog + table exponential 3.20e7 -- the short versions'
-// constants are hoisted out of the epoch loop into registers and push the point loop into spills.
+// Logarithm / exponential of the per-epoch state: the short versions (flog; the exponential through the 2^(j/256) table).
+// Measured at 1024 walkers x 3000 points, kernel time per half-step: libm + libm 12.58 us, flog + libm 12.34, libm +
+// table 12.50, flog + table 12.20.  (With machine LICM on -- before the compiler flag of the Makefile -- it was the
+// other way round: the short versions' constants were hoisted out of the epoch loop into registers and pushed the
+// point loop into spills, 3.20e7 against 3.73e7 walker-steps/s.)
 #ifndef LCF_TLOG
-#define LCF_TLOG 0   // 1 = flog, 0 = libm
+#define LCF_TLOG 1   // 1 = flog, 0 = libm
 #endif
 #ifndef LCF_TEXP
-#define LCF_TEXP 0   // 1 = through the 2^(j/256) table, 0 = libm
+#define LCF_TEXP 1   // 1 = through the 2^(j/256) table, 0 = libm
 #endif
 __device__ inline double tlog(double x) { return LCF_TLOG ? flog(x) : log(x); }
 

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else '_ZN12_GLOBAL__N_16k_soloILi5ELi1ELb1ELi2E'
+prefix = sys.argv[1] if len(sys.argv) > 1 else '_ZN12_GLOBAL__N_16k_soloILi5ELi1ELb1ELi2ELb0E'
 lines = open(os.path.join(ROOT, 'lightcurve_fitting_amd', 'csrc', 'lcf_hip.s')).read().split('\n')
 start = [i for i, l in enumerate(lines) if l.startswith(prefix)][0]
 end = next(i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end'))
