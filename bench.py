@@ -66,9 +66,10 @@ PEAK_HBM_GBS = 8000.
 VALU_PER_QUAD_F64 = 81
 VALU_PER_QUAD_F32 = 21
 # ... per data point on the interpolated path (variant 3: interval + Horner on 8 coefficients + one exponential +
-# residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (libm log + exp)
+# residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (short logarithm +
+# table exponential: 140 with libm's, and SQ_INSTS_VALU per wave -- one epoch per lane -- fell by 55 with the switch)
 VALU_PER_POINT_INTERP = 55
-VALU_PER_EPOCH_LOG = 140
+VALU_PER_EPOCH_LOG = 85
 
 
 # =====================================================================================================================
