@@ -144,6 +144,34 @@ __device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int 
 // the unstaged instantiations, so that it costs the staged kernels no registers.
 // ITAB: the instantiation may meet log-space states (engines with shared epochs only: with the thermal state inside the
 // point loop the interpolated path's registers do not fit next to it).
+// The same for TWO points of one lane, their coefficient reads issued together and the two Horner chains side by side:
+// a point is three dependent LDS round trips (state -> coefficients -> exponential table), and one after the other
+// they leave LDS and vector ALU taking turns.  Same operations per point, same results.
+__device__ __forceinline__ void interp_log_band_sum2(const DevProblem& pb, int lds_at, int ioff0, int ioff1, double r0,
+                                                     double r1, double& g0, double& g1) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int j0 = (int)r0, j1 = (int)r1;
+    const double s0 = fma(__builtin_amdgcn_fract(r0), 2., -1.), s1 = fma(__builtin_amdgcn_fract(r1), 2., -1.);
+    double2 a0, a1, a2, a3, b0, b1, b2, b3;
+    if (lds_at >= 0) {
+        const double2* qa = reinterpret_cast<const double2*>(smem + lds_at) + (ioff0 + 8 * j0) / 2;
+        const double2* qb = reinterpret_cast<const double2*>(smem + lds_at) + (ioff1 + 8 * j1) / 2;
+        a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+        b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
+    } else {
+        const double2* qa = reinterpret_cast<const double2*>(pb.itab + ioff0 + 8 * j0);
+        const double2* qb = reinterpret_cast<const double2*>(pb.itab + ioff1 + 8 * j1);
+        a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+        b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
+    }
+    double u = fma(a0.x, s0, a0.y), v = fma(b0.x, s1, b0.y);
+    u = fma(u, s0, a1.x), v = fma(v, s1, b1.x);
+    u = fma(u, s0, a1.y), v = fma(v, s1, b1.y);
+    u = fma(u, s0, a2.x), v = fma(v, s1, b2.x);
+    u = fma(u, s0, a2.y), v = fma(v, s1, b2.y);
+    u = fma(u, s0, a3.x), v = fma(v, s1, b3.x);
+    g0 = fma(u, s0, a3.y), g1 = fma(v, s1, b3.y);
+}
 template <int VARIANT, bool STAGED, bool ITAB>
 __device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
                                      const double* __restrict__ p, double t_in, int filt, const double2* tbase,
@@ -307,6 +335,25 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 const double2 yd = pb.pt_yd[i];   // (y, 1/dy), or (y, dy) when sigma is fitted
                 yv[u] = yd.x;
                 idy[u] = yd.y;
+            }
+        }
+        if (kPre == 2 && THERM && MODE == 0 && VARIANT != 0) {
+            // Two interpolated points at once, where every lane of the wave has both and all of them are inside their
+            // interpolants (the per-wave choice point_model makes point by point, for both points here): power-law
+            // models without a per-point factor.  Same arithmetic in the same order as the general code below.
+            if (pb.use_itab && pb.itab_uniform && !pb.use_sigma && (pb.model == kShockCooling || pb.model == kShockCooling2)) {
+                const bool have_both = __builtin_amdgcn_ballot_w64(idx[0] < 0 || idx[1] < 0) == 0;
+                if (have_both && __builtin_amdgcn_ballot_w64(__double2hiint(th[0].x) < 0) == 0 &&
+                    __builtin_amdgcn_ballot_w64(__double2hiint(th[1].x) < 0) == 0) {
+                    double L0, L1;
+                    interp_log_band_sum2(pb, itab_at, filt[0] * pb.itab_m * 8, filt[1] * pb.itab_m * 8, th[0].x, th[1].x, L0, L1);
+                    const double y0 = exp_scaled<false>((L0 + th[0].y) * kInvLn2N, et);
+                    const double y1 = exp_scaled<false>((L1 + th[1].y) * kInvLn2N, et);
+                    const double q0 = (yv[0] - y0) * idy[0], q1 = (yv[1] - y1) * idy[1];
+                    term = fma(q0, q0, term);
+                    term = fma(q1, q1, term);
+                    continue;
+                }
             }
         }
 #pragma unroll
