@@ -68,7 +68,11 @@ VALU_PER_QUAD_F32 = 21
 # ... per data point on the interpolated path (variant 3: interval + Horner on 8 coefficients + one exponential +
 # residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (short logarithm +
 # table exponential: 140 with libm's, and SQ_INSTS_VALU per wave -- one epoch per lane -- fell by 55 with the switch)
-VALU_PER_POINT_INTERP = 55
+# (two points of a lane are interpolated side by side since the end of round 2: interval, eight coefficients, Horner,
+# exponent, table exponential and residual take 72 vector-ALU instructions per pair; SQ_INSTS_VALU per wave fell from 795
+# to 650 with that path -- six points per lane -- because the per-point bookkeeping of the general code went with it)
+VALU_PER_POINT_INTERP = 36        # power-law models (ShockCooling, ShockCooling2): the two-point path
+VALU_PER_POINT_INTERP_GENERAL = 55  # every other model: point by point, per-wave choice of the path included
 VALU_PER_EPOCH_LOG = 85
 
 
@@ -336,8 +340,9 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
     basis = (f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x {valu_per_quad} '
              'vector-ALU instructions per quad')
     if interp is not None:
-        per_eval += interp[0] * VALU_PER_POINT_INTERP + interp[1] * VALU_PER_EPOCH_LOG
-        basis += (f' + {interp[0]:.0f} interpolated points x {VALU_PER_POINT_INTERP} + {interp[1]:.0f} log-space thermal '
+        per_point = interp[2] if len(interp) > 2 else VALU_PER_POINT_INTERP
+        per_eval += interp[0] * per_point + interp[1] * VALU_PER_EPOCH_LOG
+        basis += (f' + {interp[0]:.0f} interpolated points x {per_point} + {interp[1]:.0f} log-space thermal '
                   f'states x {VALU_PER_EPOCH_LOG}')
     shipped = evals_per_launch * per_eval
     achieved = shipped / sec / 1e12
@@ -615,7 +620,7 @@ def run_companion(args):
                 'phases': 'k_step + k_points'}[used]
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr,
                               8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 8,
-                              interp=(n_interp, 1000) if n_interp else None)
+                              interp=(n_interp, 1000, VALU_PER_POINT_INTERP_GENERAL) if n_interp else None)
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
