@@ -337,21 +337,27 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 idy[u] = yd.y;
             }
         }
-        if (kPre == 2 && THERM && MODE == 0 && VARIANT != 0) {
-            // Two interpolated points at once, where every lane of the wave has both and all of them are inside their
-            // interpolants (the per-wave choice point_model makes point by point, for both points here): power-law
-            // models without a per-point factor.  Same arithmetic in the same order as the general code below.
+        if (kPre % 2 == 0 && THERM && MODE == 0 && VARIANT != 0) {
+            // Interpolated points in PAIRS, where every lane of the wave has all its points of this round and all of
+            // them are inside their interpolants (the per-wave choice point_model makes point by point, for all of
+            // them here): power-law models without a per-point factor.  Same arithmetic in the same order as the
+            // general code below.
             if (pb.use_itab && pb.itab_uniform && !pb.use_sigma && (pb.model == kShockCooling || pb.model == kShockCooling2)) {
-                const bool have_both = __builtin_amdgcn_ballot_w64(idx[0] < 0 || idx[1] < 0) == 0;
-                if (have_both && __builtin_amdgcn_ballot_w64(__double2hiint(th[0].x) < 0) == 0 &&
-                    __builtin_amdgcn_ballot_w64(__double2hiint(th[1].x) < 0) == 0) {
-                    double L0, L1;
-                    interp_log_band_sum2(pb, itab_at, filt[0] * pb.itab_m * 8, filt[1] * pb.itab_m * 8, th[0].x, th[1].x, L0, L1);
-                    const double y0 = exp_scaled<false>((L0 + th[0].y) * kInvLn2N, et);
-                    const double y1 = exp_scaled<false>((L1 + th[1].y) * kInvLn2N, et);
-                    const double q0 = (yv[0] - y0) * idy[0], q1 = (yv[1] - y1) * idy[1];
-                    term = fma(q0, q0, term);
-                    term = fma(q1, q1, term);
+                bool general = false;
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) general = general || idx[u] < 0 || __double2hiint(th[u].x) < 0;
+                if (__builtin_amdgcn_ballot_w64(general) == 0) {
+#pragma unroll
+                    for (int u = 0; u < kPre; u += 2) {
+                        double L0, L1;
+                        interp_log_band_sum2(pb, itab_at, filt[u] * pb.itab_m * 8, filt[u + 1] * pb.itab_m * 8, th[u].x,
+                                             th[u + 1].x, L0, L1);
+                        const double y0 = exp_scaled<false>((L0 + th[u].y) * kInvLn2N, et);
+                        const double y1 = exp_scaled<false>((L1 + th[u + 1].y) * kInvLn2N, et);
+                        const double q0 = (yv[u] - y0) * idy[u], q1 = (yv[u + 1] - y1) * idy[u + 1];
+                        term = fma(q0, q0, term);
+                        term = fma(q1, q1, term);
+                    }
                     continue;
                 }
             }
