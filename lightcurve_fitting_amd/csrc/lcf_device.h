@@ -76,7 +76,16 @@ struct DevProblem {
     const double* itab;   // [n_filters][itab_m][8], highest power first
     int part_start[kMaxParts + 1];  // part j owns the points [part_start[j], part_start[j+1]): whole epochs ...
     int part_ep0[kMaxParts + 1];    // ... namely the epochs [part_ep0[j], part_ep0[j+1]) (when use_therm)
-    int pad4[2];
+    // Epoch-major copy of the photometry (engines with use_therm; the likelihood walks it, one lane per COLUMN): a column
+    // is one observation time with up to em_k of its points, ordered by filter; an epoch with more points than that
+    // takes several columns.  The lane computes the column's thermal state once, in registers, and loops over the
+    // column's points: em_yd / em_filt are [em_k][em_cols] (consecutive lanes read consecutive addresses).
+    int part_col0[kMaxParts + 1];   // part j owns the columns [part_col0[j], part_col0[j+1])
+    int em_k, em_cols;
+    int em_dense;                   // every column holds exactly one point of every filter, in filter order
+    const double* em_t;             // [em_cols] observation time
+    const double2* em_yd;           // [em_k][em_cols] (y, 1/dy), or (y, dy) when sigma is fitted
+    const int* em_filt;             // [em_k][em_cols] filter index, -1 = no point
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double knot_inv_h;      // 1 / spacing of the spline knots when they are equally spaced (to 1e-9), else 0
@@ -271,18 +280,22 @@ __device__ inline double band_sum_fast(TabPtr tab, int cnt, double invT, const E
 // `lq[d]` = log(p[d]) for d < n_par (may be NaN/-inf where p[d] <= 0: only used when the parameter is positive).
 // `log_only`: the caller's thermal states stay in log space (thermal_state_log of a power-law model): the linear
 // amplitudes c[1], c[2] -- one exponential each -- are then not needed and are left NaN.
+// MODEL > 0: the model is a compile-time constant (kernels specialised for one model: the other models' code is not
+// even in the instruction stream); 0: pb.model decides at run time.
+template <int MODEL = 0>
 __device__ inline void walker_coefficients(const DevProblem& pb, const double* __restrict__ p,
                                            const double* __restrict__ lq, double* __restrict__ c,
                                            bool log_only = false) {
     const double* k = pb.consts;
+    const int model = MODEL ? MODEL : pb.model;
     for (int i = 0; i < kNCoef; ++i) c[i] = 0.;
-    if (pb.model != kShockCooling3) c[6] = c[7] = qnan();
-    switch (pb.model) {
+    if (model != kShockCooling3) c[6] = c[7] = qnan();
+    switch (model) {
         case kShockCooling:
         case kShockCooling3: {  // models.py:260-267; ShockCooling3 (models.py:493-495): + distance and reddening
             const double A = k[0], a = k[1], alpha = k[2], eps1 = k[3], eps2 = k[4], L0 = k[5], T0 = k[6], ratio = k[7];
             const double v = p[0], M = p[1], f = p[2], R = p[3];
-            if (pb.model == kShockCooling3) {
+            if (model == kShockCooling3) {
                 c[0] = p[6];
                 c[5] = kC4 / (p[4] * p[4]);  // flux = c4 * lum / dist ** 2
                 c[6] = p[5];                 // E(B-V): scales the band-table weights (points_body)
@@ -293,12 +306,12 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
                 // all bases positive: every power() is a plain power; share the four logarithms
                 const double lv = lq[0], lM = lq[1], lf = lq[2], lR = lq[3];
                 const double a1 = eps1 * (2. * lv - lf) + 0.25 * lR, a2 = -eps2 * (lv - lf) + 2. * lv + lR;
-                const bool skip = log_only && pb.model == kShockCooling;
+                const bool skip = log_only && model == kShockCooling;
                 c[1] = skip ? qnan() : (T0 * ratio / kKB) * exp(a1);
                 c[2] = skip ? qnan() : (L0 * A) * exp(a2);
                 c[3] = a > 0. ? alpha * (k[11] - 0.5 * (lM - lv)) : qnan();  // k[11] = ln(a / 19.5), set at create
                 c[4] = 0.;
-                if (pb.model == kShockCooling) {  // k[9] = ln(T0 ratio / k_B), k[10] = ln(c3^2 L0 A), set at create
+                if (model == kShockCooling) {  // k[9] = ln(T0 ratio / k_B), k[10] = ln(c3^2 L0 A), set at create
                     c[6] = k[9] + a1;
                     c[7] = k[10] + a2;
                 }
@@ -311,7 +324,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             c[2] = Lc * A;
             c[3] = g > 0. ? alpha * log(g) : qnan();
             c[4] = (Lc >= 0.) ? 0. : 1.;
-            if (pb.model == kShockCooling) {
+            if (model == kShockCooling) {
                 c[6] = (c[1] > 0. && c[1] < INFINITY) ? log(c[1]) : qnan();
                 c[7] = (c[2] >= 0. && c[2] < INFINITY) ? log(kC3sq * c[2]) : qnan();
             }
@@ -349,10 +362,10 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
         case kCompanion2:
         case kCompanion3: {  // models.py:752-755, 1040-1044
             const double a13 = p[1];
-            const double Mv = pb.model == kCompanion3 ? 1. : p[2];
+            const double Mv = model == kCompanion3 ? 1. : p[2];
             c[0] = p[0];
             if (a13 > 0. && Mv > 0. && a13 < 1e8 && a13 > 1e-8 && Mv < 1e100) {
-                const double la = lq[1], lm = pb.model == kCompanion3 ? 0. : lq[2];
+                const double la = lq[1], lm = model == kCompanion3 ? 0. : lq[2];
                 c[1] = log_only ? qnan() : 25. * exp((36. * la + lm) * (1. / 144.));
                 c[2] = log_only ? qnan() : 7.29 * exp(lm * (2. / 9.));
                 c[6] = 3.2188758248682006 + (36. * la + lm) * (1. / 144.);  // ln 25
@@ -366,7 +379,7 @@ __device__ inline void walker_coefficients(const DevProblem& pb, const double* _
             }
             c[3] = p[3];
             c[4] = p[4];
-            if (pb.model == kCompanion3) {
+            if (model == kCompanion3) {
                 const double th = p[2] * 0.017453292519943295;
                 c[5] = (0.5 * cos(th) + 0.5) * (0.14 * th * th - 0.4 * th + 1.);
             } else {
@@ -441,14 +454,16 @@ __device__ inline double inv_temperature(double Tk) {  // 1 / Tk for 0 < Tk < kT
     return 1. / Tk;
 }
 
+template <int MODEL = 0>
 __device__ inline void thermal_state(const DevProblem& pb, const double* __restrict__ c, double t_in, double& T,
                                      double& invT, double& pref) {
     const double* k = pb.consts;
+    const int model = MODEL ? MODEL : pb.model;
     const double t = t_in - c[0];
     T = 0.;
     invT = 0.;
     pref = 0.;
-    switch (pb.model) {
+    switch (model) {
         case kShockCooling:
         case kShockCooling2:
         case kShockCooling3: {
@@ -553,30 +568,41 @@ __device__ inline void encode_linear(double invT, double pref, double& x, double
     p = pref;
 }
 
+// Log-space state of a power-law model (ShockCooling, ShockCooling2) at a POSITIVE phase t: u = ln T_K and lp = ln R_bb^2
+// from one logarithm and at most one exponential; lL = ln(c3^2 L), NaN where L < 0 or NaN (and everything is NaN for
+// t <= 0: the callers decide on the phase themselves).  c3, c6, c7 = the walker's coefficients c[3], c[6], c[7].
+__device__ __forceinline__ void powerlaw_log_state(const DevProblem& pb, double c3, double c6, double c7, double t,
+                                                   const ExpTab et, double& u, double& lp, double& lL) {
+    const double* k = pb.consts;
+    const double eps1 = k[3], eps2 = k[4], alpha = k[2];
+    const double lt = tlog(t);
+    // (the exponential through the 2^(j/256) table: same arithmetic whether `et` points to LDS or memory)
+    const double E = !(c3 == c3) ? 0.
+                     : LCF_TEXP ? exp_scaled<true>(fma(alpha, lt, c3) * kInvLn2N, et)
+                                : exp(fma(alpha, lt, c3));
+    lL = fma(-2. * eps2, lt, c7) - E;
+    u = fma(2. * eps1 - 0.5, lt, c6);
+    lp = fma(-4., u, lL);
+}
+
+template <int MODEL = 0>
 __device__ inline void thermal_state_log(const DevProblem& pb, const double* __restrict__ c, double t_in, double& x,
                                          double& p, const ExpTab et) {
-    const double* k = pb.consts;
+    const int model = MODEL ? MODEL : pb.model;
     const double t = t_in - c[0];
     x = -0.;
     p = 0.;
     double u = qnan(), lp = 0.;  // ln T, ln R_bb^2 when both exist
-    switch (pb.model) {
+    switch (model) {
         case kShockCooling:
         case kShockCooling2: {
-            const double eps1 = k[3], eps2 = k[4], alpha = k[2];
             if (t > 0.) {
-                const double lt = tlog(t);
-                // (the exponential through the 2^(j/256) table: same arithmetic whether `et` points to LDS or memory)
-                const double E = !(c[3] == c[3]) ? 0.
-                                 : LCF_TEXP ? exp_scaled<true>(fma(alpha, lt, c[3]) * kInvLn2N, et)
-                                            : exp(fma(alpha, lt, c[3]));
-                const double lL = fma(-2. * eps2, lt, c[7]) - E;  // ln(c3^2 L)
+                double lL;
+                powerlaw_log_state(pb, c[3], c[6], c[7], t, et, u, lp, lL);
                 if (!(lL == lL)) {
                     p = qnan();          // L < 0 or NaN
                     return;
                 }
-                u = fma(2. * eps1 - 0.5, lt, c[6]);
-                lp = fma(-4., u, lL);
             } else {
                 if (t < 0. && c[4] != 0.) p = qnan();  // sqrt(L) with L < 0 before the explosion
                 return;
@@ -596,7 +622,7 @@ __device__ inline void thermal_state_log(const DevProblem& pb, const double* __r
         }
         default: {  // ShockCooling4, Blackbody: linear-space state, then two logarithms
             double T, invT, pref;
-            thermal_state(pb, c, t_in, T, invT, pref);
+            thermal_state<MODEL>(pb, c, t_in, T, invT, pref);
             if (T > 0. && pref > 0. && pref < INFINITY) {
                 u = log(T);
                 lp = log(pref);

@@ -44,6 +44,9 @@
 #ifndef LCF_FIRST_BLOCK
 #define LCF_FIRST_BLOCK 32  // steps in the first block of draw records of a run (the later ones: up to 256)
 #endif
+#ifndef LCF_HEAD_START
+#define LCF_HEAD_START 0  // k_solo: the waves beside the serial head wait 64 x this many cycles before their first loads
+#endif
 #ifndef LCF_WAVES
 #define LCF_WAVES 4  // occupancy the register allocator is asked to keep (waves per SIMD)
 #endif
@@ -64,10 +67,24 @@ __device__ __forceinline__ double lane_value(double v, int lane) {
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
 }
 
+// v of the lane the DPP control names (a compile-time lane pattern inside a row of 16 lanes), two 32-bit moves
+template <int CTRL>
+__device__ __forceinline__ double dpp_value(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+// Sum over the 64 lanes of a wave, the same number in every lane, in a fixed order: inside quads (lane ^ 1, lane ^ 2), the
+// two quads of a row half (mirror of 8), the two halves of a row (mirror of 16) -- data-parallel moves between vector
+// registers, no LDS round trip as a shuffle is -- then the four rows (r0 + r1) + (r2 + r3) through scalar registers.
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_value<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_value<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_value<0x141>(v);   // row_half_mirror
+    v += dpp_value<0x140>(v);   // row_mirror
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // One thread per walker: derived coefficients, log-prior, skip flag.
@@ -144,38 +161,13 @@ __device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int 
 // the unstaged instantiations, so that it costs the staged kernels no registers.
 // ITAB: the instantiation may meet log-space states (engines with shared epochs only: with the thermal state inside the
 // point loop the interpolated path's registers do not fit next to it).
-// The same for TWO points of one lane, their coefficient reads issued together and the two Horner chains side by side:
-// a point is three dependent LDS round trips (state -> coefficients -> exponential table), and one after the other
-// they leave LDS and vector ALU taking turns.  Same operations per point, same results.
-__device__ __forceinline__ void interp_log_band_sum2(const DevProblem& pb, int lds_at, int ioff0, int ioff1, double r0,
-                                                     double r1, double& g0, double& g1) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int j0 = (int)r0, j1 = (int)r1;
-    const double s0 = fma(__builtin_amdgcn_fract(r0), 2., -1.), s1 = fma(__builtin_amdgcn_fract(r1), 2., -1.);
-    double2 a0, a1, a2, a3, b0, b1, b2, b3;
-    if (lds_at >= 0) {
-        const double2* qa = reinterpret_cast<const double2*>(smem + lds_at) + (ioff0 + 8 * j0) / 2;
-        const double2* qb = reinterpret_cast<const double2*>(smem + lds_at) + (ioff1 + 8 * j1) / 2;
-        a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-        b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-    } else {
-        const double2* qa = reinterpret_cast<const double2*>(pb.itab + ioff0 + 8 * j0);
-        const double2* qb = reinterpret_cast<const double2*>(pb.itab + ioff1 + 8 * j1);
-        a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-        b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-    }
-    double u = fma(a0.x, s0, a0.y), v = fma(b0.x, s1, b0.y);
-    u = fma(u, s0, a1.x), v = fma(v, s1, b1.x);
-    u = fma(u, s0, a1.y), v = fma(v, s1, b1.y);
-    u = fma(u, s0, a2.x), v = fma(v, s1, b2.x);
-    u = fma(u, s0, a2.y), v = fma(v, s1, b2.y);
-    u = fma(u, s0, a3.x), v = fma(v, s1, b3.x);
-    g0 = fma(u, s0, a3.y), g1 = fma(v, s1, b3.y);
-}
-template <int VARIANT, bool STAGED, bool ITAB>
+// MODEL > 0: compile-time model of an engine whose interpolants are all proved from their first interval
+// (DevProblem::itab_uniform) and which fits no sigma -- the kernels specialised for the benchmark shapes.
+template <int VARIANT, bool STAGED, bool ITAB, int MODEL = 0>
 __device__ __forceinline__ double point_model(const DevProblem& pb, const double* __restrict__ c,
                                      const double* __restrict__ p, double t_in, int filt, const double2* tbase,
                                      const FiltDesc* fdesc, const ExpTab et, double invT, double pref, int itab_at) {
+    const int model = MODEL ? MODEL : pb.model;
     double S = 0., yfit;
     const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt;  // the filter's descriptor: three 16-byte reads
     // Log-space state (x = ln T > 0, pref = ln R_bb^2; see thermal_state_log): the interpolant if every point of the
@@ -183,14 +175,14 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     // result never depends on how walkers are batched -- else the sample tables after one exponential each.
     bool by_table = false;
     int ioff = filt * pb.itab_m * 8;
-    if (ITAB && VARIANT != 0 && pb.use_itab) {
+    if (ITAB && VARIANT != 0 && (MODEL || pb.use_itab)) {
         const bool log_form = __double2hiint(invT) >= 0;   // (-0.0 and -1/T have the sign bit set)
         bool inside = log_form;
-        if (!pb.itab_uniform || pb.model == kShockCooling4) {
+        if ((!MODEL && !pb.itab_uniform) || model == kShockCooling4) {
             const long long fmeta = __double_as_longlong(fd[1].y);   // {float r_min, int ioff} of the filter's interpolant
             ioff = (int)(fmeta >> 32);
             // (ShockCooling4 also needs the band sum at 0.74 T: ln 0.74 / h intervals lower)
-            const double r_low = pb.model == kShockCooling4 ? invT - 0.3011050927839216 * pb.itab_inv_h : invT;
+            const double r_low = model == kShockCooling4 ? invT - 0.3011050927839216 * pb.itab_inv_h : invT;
             inside = log_form && r_low >= (double)__int_as_float((int)fmeta);
         }
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
@@ -204,10 +196,10 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     }
     if (by_table) {
         double L = interp_log_band_sum(pb, itab_at, ioff, invT);
-        if (pb.model == kShockCooling4)  // min(blackbody, suppressed blackbody at 0.74 T), models.py:629-631
+        if (model == kShockCooling4)  // min(blackbody, suppressed blackbody at 0.74 T), models.py:629-631
             L = fmin(L, interp_log_band_sum(pb, itab_at, ioff, invT - 0.3011050927839216 * pb.itab_inv_h) + 1.2044203711356864);
         // (|ln R_bb^2| <= 600 and |ln S| < 100: the exponent can be added as an integer)
-        yfit = exp_scaled<false>((L + pref) * kInvLn2N, et);
+        yfit = exp_scaled<false>(fma(L, kInvLn2N, pref * kInvLn2N), et);
     } else if (!STAGED && invT > 0. && pb.redden_slow) {
         // ShockCooling3 through tables too long for LDS: the walker's reddening is applied sample by sample to the
         // full table in global memory (libm; a fall-back, not a fast path)
@@ -223,15 +215,15 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
                                         __double_as_longlong(d1.x), d2.x, d2.y, pb.tab,
                                         STAGED ? pb.n_lds_tab : 0x7fffffff};
         S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT, et);
-        if (pb.model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
+        if (model == kShockCooling4) {  // models.py:629-631: min(blackbody, suppressed blackbody)
             const double S2 = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, invT * (1. / 0.74), et);
             S = fmin(S, S2 * (1. / (0.74 * 0.74 * 0.74 * 0.74)));
         }
     }
     // pref may be NaN (propagates) or 0 with 1/T == 0.
     if (!by_table) yfit = (pref != pref) ? pref : pref * S;
-    if (pb.model == kShockCooling3) yfit *= c[5];  // models.py:495
-    if (pb.model >= kCompanion && pb.model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
+    if (model == kShockCooling3) yfit *= c[5];  // models.py:495
+    if (model >= kCompanion && model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
         const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
         const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
         const double sfac = sp >= 0 ? p[sp] : 1.;
@@ -241,6 +233,312 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
         yfit = yfit * kfac + tmpl * sfac;
     }
     return yfit;
+}
+
+// Diagnostic build only (-DLCF_STAMPS, tools/debug/make_stamp_build.py; never shipped): s_memtime stamps of the first 64
+// workgroups of k_solo, written by the first lane of wave `W` into a buffer nothing else reads.
+#ifdef LCF_STAMPS
+__device__ unsigned long long g_wall[2 * 1024 * 2];   // [launch parity][workgroup][entry, exit] of the 100 MHz wall clock
+__device__ unsigned long long g_stamps[64 * 16];
+#define LCF_STAMP(W, k)                                                                                        \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) g_stamps[blockIdx.x * 16 + (k)] = t_;                  \
+    } while (0)
+#else
+#define LCF_STAMP(W, k) do {} while (0)
+#endif
+
+// ---- epoch-major likelihood: one lane per COLUMN (an observation time and its points, DevProblem::em_*) ----------------
+// The lane computes the column's thermal state in registers and walks the column's points itself: no hand-off of the
+// state through LDS, no barrier between states and points, one interval / position of the temperature for all filters
+// of the epoch, and as many independent Horner chains per lane as the epoch has filters.
+//
+// M filters side by side for one column on the interpolated level: filters f0 .. f0 + M - 1 (wave-uniform: the column
+// layout is dense), interval j and position s shared by all of them.  Returns y_fit per filter.  `row` = the lane's
+// offset 8 j (doubles) inside a filter's interpolant; a filter's interpolant is 8 itab_m doubles long.
+// IN_LDS: the interpolants are staged at byte `lds_at` of the dynamic LDS (the address is formed from the LDS symbol
+// itself, so that the reads are ds_read_b128 with immediate offsets and not generic-pointer loads); else global memory.
+// (A compile-time choice: with both in one function the two sets of loads share registers, and the LDS reads then wait
+// for every outstanding global load -- the column's own photometry included.)
+// `lnr2k` = ln R_bb^2 x 256 / ln 2: y_fit = 2^((ln S + ln R_bb^2) 256 / ln 2 / 256), the scaling folded into one FMA.
+template <int M, bool IN_LDS>
+__device__ __forceinline__ void interp_columns(const DevProblem& pb, int lds_at, int f0, int row, double s, double lnr2k,
+                                               const ExpTab et, double (&yfit)[M]) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 q[M][4];
+    const int fstride = pb.itab_m * 8;
+    if (IN_LDS) {
+        const double2* base = reinterpret_cast<const double2*>(smem + lds_at) + row / 2;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double2* qa = base + ((f0 + m) * fstride) / 2;
+            q[m][0] = qa[0], q[m][1] = qa[1], q[m][2] = qa[2], q[m][3] = qa[3];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const double2* qa = reinterpret_cast<const double2*>(pb.itab + (size_t)(f0 + m) * fstride) + row / 2;
+            q[m][0] = qa[0], q[m][1] = qa[1], q[m][2] = qa[2], q[m][3] = qa[3];
+        }
+    }
+    double g[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(q[m][0].x, s, q[m][0].y);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][1].x);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][1].y);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][2].x);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][2].y);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][3].x);
+#pragma unroll
+    for (int m = 0; m < M; ++m) g[m] = fma(g[m], s, q[m][3].y);
+    // (|ln R_bb^2| <= 600 and |ln S| < 100: the exponent can be added as an integer)
+#pragma unroll
+    for (int m = 0; m < M; ++m) yfit[m] = exp_scaled<false>(fma(g[m], kInvLn2N, lnr2k), et);
+}
+
+// What a lane needs of its FIRST column before any arithmetic: the observation time and (dense columns of up to kPreK
+// filters) the photometry.  None of it depends on the proposal, so the one-launch half-step kernels fetch it ahead of
+// the serial head: by the time the coefficients exist the loads have long landed.
+constexpr int kPreK = 6;
+struct ColumnOperands {
+    double t;
+    double2 o[kPreK];
+    bool have_o;   // (wave-uniform)
+};
+
+template <int MODEL = 0>
+__device__ __forceinline__ bool columns_fast_kind(const DevProblem& pb, bool by_itab) {
+    if (MODEL) return true;   // (what a model-specialised kernel is launched for)
+    // dense columns of a power-law model without a fitted sigma and with interpolants proved from their first interval:
+    // every point of a wave whose states are all in log space goes through interp_columns
+    return by_itab && pb.em_dense && pb.itab_uniform && !pb.use_sigma && (pb.model == kShockCooling || pb.model == kShockCooling2);
+}
+
+template <int VARIANT, int MODEL = 0>
+__device__ __forceinline__ void fetch_column(const DevProblem& pb, int part, int vtid, ColumnOperands& co) {
+    const int c0 = part_entry(pb.part_col0, part), c1 = part_entry(pb.part_col0, part + 1);
+    const int cb = c0 + (vtid & ~63), lane = vtid & 63;
+    co.have_o = false;
+    co.t = 0.;
+#pragma unroll
+    for (int k = 0; k < kPreK; ++k) co.o[k] = make_double2(0., 0.);
+    if (cb >= c1) return;
+    const int col = min(cb + lane, c1 - 1);
+    co.t = pb.em_t[col];
+    if (columns_fast_kind<MODEL>(pb, VARIANT != 0 && pb.use_itab) && pb.em_k == kPreK) {
+        co.have_o = true;
+#pragma unroll
+        for (int k = 0; k < kPreK; ++k) co.o[k] = pb.em_yd[(size_t)k * pb.em_cols + col];
+    }
+}
+
+// The interpolated points of one dense column (the lane's): sum of squared scaled residuals.
+// ... of kPreK filters whose photometry is in registers already (fetch_column): two groups of three, all operands at hand
+template <bool IN_LDS>
+__device__ __forceinline__ double fast_column_fetched(const DevProblem& pb, int itab_at, int row, double s, double lnr2k,
+                                                      const ExpTab et, const double2 (&o)[kPreK]) {
+    static_assert(kPreK == 6, "two groups of three");
+    double acc = 0.;
+#pragma unroll
+    for (int f = 0; f < kPreK; f += 3) {
+        double yf[3];
+        interp_columns<3, IN_LDS>(pb, itab_at, f, row, s, lnr2k, et, yf);
+        const double q0 = (o[f].x - yf[0]) * o[f].y, q1 = (o[f + 1].x - yf[1]) * o[f + 1].y;
+        const double q2 = (o[f + 2].x - yf[2]) * o[f + 2].y;
+        acc = fma(q0, q0, acc);
+        acc = fma(q1, q1, acc);
+        acc = fma(q2, q2, acc);
+        LCF_STAMP(0, 14 + (f > 0));
+    }
+    return acc;
+}
+// ... of any number of filters, photometry fetched group by group
+template <bool IN_LDS>
+__device__ __forceinline__ double fast_column(const DevProblem& pb, int itab_at, int col, int row, double s, double lnr2k,
+                                              const ExpTab et) {
+    const int nf = pb.em_k, nc = pb.em_cols;
+    const double2* yd = pb.em_yd + col;
+    double acc = 0.;
+    int f = 0;
+#pragma unroll 1
+    for (; f + 3 <= nf; f += 3) {
+        const double2 o0 = yd[(size_t)f * nc], o1 = yd[(size_t)(f + 1) * nc], o2 = yd[(size_t)(f + 2) * nc];
+        double yf[3];
+        interp_columns<3, IN_LDS>(pb, itab_at, f, row, s, lnr2k, et, yf);
+        const double q0 = (o0.x - yf[0]) * o0.y, q1 = (o1.x - yf[1]) * o1.y, q2 = (o2.x - yf[2]) * o2.y;
+        acc = fma(q0, q0, acc);
+        acc = fma(q1, q1, acc);
+        acc = fma(q2, q2, acc);
+    }
+    if (f + 2 <= nf) {
+        const double2 o0 = yd[(size_t)f * nc], o1 = yd[(size_t)(f + 1) * nc];
+        double yf[2];
+        interp_columns<2, IN_LDS>(pb, itab_at, f, row, s, lnr2k, et, yf);
+        const double q0 = (o0.x - yf[0]) * o0.y, q1 = (o1.x - yf[1]) * o1.y;
+        acc = fma(q0, q0, acc);
+        acc = fma(q1, q1, acc);
+        f += 2;
+    }
+    if (f < nf) {
+        const double2 o0 = yd[(size_t)f * nc];
+        double yf[1];
+        interp_columns<1, IN_LDS>(pb, itab_at, f, row, s, lnr2k, et, yf);
+        const double q0 = (o0.x - yf[0]) * o0.y;
+        acc = fma(q0, q0, acc);
+    }
+    return acc;
+}
+
+// One column point by point: any model, fitted sigma, states outside the interpolants, ragged columns.  `dense`: the
+// filter index is the loop counter (wave-uniform, scalar table loads).  The ballots inside point_model see the lanes
+// that have a point at this position of their column only.
+template <int VARIANT, bool LDS_TAB, int MODEL>
+__device__ __forceinline__ double general_column(const DevProblem& pb, const double* __restrict__ p,
+                                                  const double* __restrict__ c, const double2* tbase, const FiltDesc* fdesc,
+                                                  const ExpTab et, int itab_at, double t_in, int col, bool live, double x,
+                                                  double pr) {
+    const int nc = pb.em_cols;
+    double acc = 0.;
+    auto one_point = [&](int k, int filt) {
+        const double2 o = pb.em_yd[(size_t)k * nc + col];
+        const double yfit = point_model<VARIANT, LDS_TAB, true, MODEL>(pb, c, p, t_in, filt, tbase, fdesc, et, x, pr, itab_at);
+        const double r = o.x - yfit;   // models.py:121-135
+        if (!MODEL && pb.use_sigma) {
+            const double dy = o.y;
+            const double su = p[pb.n_dim - 1] * (pb.sigma_abs ? pb.sigma_unit_abs : dy);
+            const double var = fma(dy, dy, su * su);
+            acc += log(kTwoPi * var) + r * r / var;
+        } else {
+            const double q = r * o.y;
+            acc = fma(q, q, acc);
+        }
+    };
+    if (MODEL || pb.em_dense) {
+#pragma unroll 1
+        for (int k = 0; k < pb.em_k; ++k)
+            if (live) one_point(k, k);
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < pb.em_k; ++k) {
+            const int filt = pb.em_filt[(size_t)k * nc + col];
+            if (live && filt >= 0) one_point(k, filt);
+        }
+    }
+    return acc;
+}
+
+// The same for a MODEL-SPECIALISED kernel, out of line: a wave of such a kernel gets here when one of its states is
+// outside the interpolants (a phase before the explosion, a temperature outside 2..256 kK) -- rare in a fit, and inlined the
+// sample-table code would sit in the kernel's instruction stream and register budget.  Tables, descriptors and the exp
+// table are read from global memory (the numbers their staged copies hold), the coefficients through a plain pointer:
+// no LDS symbol in here.
+template <int VARIANT, int MODEL>
+__device__ __attribute__((noinline)) double cold_column(const DevProblem* pbp, const double* c_mem, const double* p, double t_in,
+                                                        int col, bool live, double x, double pr) {
+    const DevProblem& pb = *pbp;
+    double c[kNCoef];
+#pragma unroll
+    for (int k = 0; k < kNCoef; ++k) c[k] = c_mem[k];
+    return general_column<VARIANT, false, MODEL>(pb, p, c, pb.tab, pb.f_desc, ExpTab{pb.exp2tab}, -1, t_in, col, live, x, pr);
+}
+
+// ... computing the state of the column itself (for the caller that found the wave outside the fast path before it had one)
+template <int VARIANT, int MODEL>
+__device__ __attribute__((noinline)) double cold_column_with_state(const DevProblem* pbp, const double* c_mem, const double* p,
+                                                                   double t_in, int col, bool live) {
+    const DevProblem& pb = *pbp;
+    double c[kNCoef], x, pr;
+#pragma unroll
+    for (int k = 0; k < kNCoef; ++k) c[k] = c_mem[k];
+    const ExpTab et{pb.exp2tab};
+    thermal_state_log<MODEL>(pb, c, t_in, x, pr, et);
+    return general_column<VARIANT, false, MODEL>(pb, p, c, pb.tab, pb.f_desc, et, -1, t_in, col, live, x, pr);
+}
+
+// The whole column phase of a lane of a MODEL-specialised kernel in the shape the benchmarks have -- a power-law model,
+// kPreK filters, the lane's one column already fetched (fetch_column), interpolants in LDS: straight-line code, the five
+// coefficients the state needs as vector registers (no scalar copies, nothing hoisted).  The arithmetic is epochs_loop's
+// fast branch, operation for operation.  Returns false (wave-uniform) where a state of the wave is outside the
+// interpolants: the caller then takes the general path for the column.
+template <int MODEL>
+__device__ __forceinline__ bool lean_column(const DevProblem& pb, const double* __restrict__ sc, const ColumnOperands& first,
+                                            const ExpTab et, int itab_at, double& acc) {
+    const double t = first.t - sc[0];
+    double u, lp, lL;
+    powerlaw_log_state(pb, sc[3], sc[6], sc[7], t, et, u, lp, lL);
+    const double r = (u - pb.itab_u0) * pb.itab_inv_h;
+    // exactly where thermal_state_log leaves a log-space pair (lL NaN makes lp NaN: every comparison fails)
+    const bool ok = t > 0. && r >= 0. && r < (double)pb.itab_m && lp >= -600. && lp <= 600.;
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return false;
+    const int row = 8 * (int)r;
+    const double s = fma(__builtin_amdgcn_fract(r), 2., -1.);
+    acc = fast_column_fetched<true>(pb, itab_at, row, s, lp * kInvLn2N, et, first.o);
+    return true;
+}
+
+// chi^2 share of virtual thread `vtid` (0 .. kBlock-1) of part `part` for one walker: parameters p, coefficients c.
+// Virtual wave v = vtid / 64 owns the columns part_col0 + 64 v + lane + 256 m, m = 0, 1, ...: whichever kernel walks a
+// part (k_points, k_fused, k_solo, k_pop) and whichever physical wave plays virtual wave v, the lane sums, the wave
+// sums (xor butterfly) and the part's sum (w0 + w1) + (w2 + w3) are the same numbers -- chains do not depend on the kernel.
+// The band-sum path (interpolant or sample tables; fast or safe exponentials) is chosen per wave, for the filter the wave
+// is at: deterministic in the walker and the light curve alone.
+// `first` (when FETCHED): the operands of the lane's first column, fetched by the caller (fetch_column, this part and vtid).
+// COLD (model-specialised kernels that hold the problem in memory, `pb_mem`, and the coefficients at `c_mem`): the
+// general path is the out-of-line cold_column.
+template <int VARIANT, bool LDS_TAB, bool FETCHED = false, int MODEL = 0, bool COLD = false>
+__device__ inline double epochs_loop(const DevProblem& pb, int part, const double* __restrict__ p,
+                                     const double* __restrict__ c, const double2* tbase, const FiltDesc* fdesc,
+                                     const ExpTab et, int vtid, int itab_at, const ColumnOperands& first = ColumnOperands{},
+                                     bool use_first = true, const DevProblem* pb_mem = nullptr,
+                                     const double* c_mem = nullptr) {
+    // (`part` and the virtual wave are wave-uniform: scalar registers)
+    part = __builtin_amdgcn_readfirstlane(part);
+    const int c0 = part_entry(pb.part_col0, part), c1 = part_entry(pb.part_col0, part + 1);
+    const int lane = vtid & 63, v64 = __builtin_amdgcn_readfirstlane(vtid & ~63);
+    const bool by_itab = MODEL ? true : VARIANT != 0 && pb.use_itab;
+    const bool fast_kind = columns_fast_kind<MODEL>(pb, by_itab);
+    double term = 0.;
+#pragma unroll 1
+    for (int cb = c0 + v64; cb < c1; cb += kBlock) {
+        const bool live = cb + lane < c1;
+        const int col = live ? cb + lane : c1 - 1;   // lanes beyond the part repeat its last column; their terms are dropped
+        const bool fetched = FETCHED && use_first && cb < c0 + kBlock;
+        const double t_in = fetched ? first.t : pb.em_t[col];
+        double x, pr;   // the log-space pair of thermal_state_log, or (1/T, R_bb^2)
+        if (by_itab) {
+            thermal_state_log<MODEL>(pb, c, t_in, x, pr, et);
+        } else {
+            double T;
+            thermal_state<MODEL>(pb, c, t_in, T, x, pr);
+        }
+        LCF_STAMP(0, 13);
+        if (fast_kind && __builtin_amdgcn_ballot_w64(__double2hiint(x) < 0) == 0) {
+            const int row = 8 * (int)x;
+            const double s = fma(__builtin_amdgcn_fract(x), 2., -1.);
+            const double lnr2k = pr * kInvLn2N;
+            double acc;
+            if (fetched && first.have_o)
+                acc = itab_at >= 0 ? fast_column_fetched<true>(pb, itab_at, row, s, lnr2k, et, first.o)
+                                   : fast_column_fetched<false>(pb, itab_at, row, s, lnr2k, et, first.o);
+            else
+                acc = itab_at >= 0 ? fast_column<true>(pb, itab_at, col, row, s, lnr2k, et)
+                                   : fast_column<false>(pb, itab_at, col, row, s, lnr2k, et);
+            term += live ? acc : 0.;   // (a dead lane's sum is dropped as a whole)
+            continue;
+        }
+        if constexpr (COLD && MODEL != 0)
+            term += cold_column<VARIANT, MODEL>(pb_mem, c_mem, p, t_in, col, live, x, pr);
+        else
+            term += general_column<VARIANT, LDS_TAB, MODEL>(pb, p, c, tbase, fdesc, et, itab_at, t_in, col, live, x, pr);
+    }
+    return term;
 }
 
 // Thermal state (T, R_bb^2) of every (walker, distinct observation time): light curves observed in several filters at
@@ -290,15 +588,17 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
     }
 }
 
-// The points of part `part` for one walker: parameters p, coefficients c (global or LDS), thermal states
-// th[pt_epoch - e_off] when THERM.  MODE 0: returns this thread's share of chi^2;  MODE 1: y_fit -> out0[row][orig];
-// MODE 2: T, R_bb -> out0, out1.
+// The points of part `part` for one walker in the filter-sorted order: parameters p, coefficients c (global or LDS),
+// thermal states th[pt_epoch - e_off] when THERM.  MODE 0: returns this thread's share of chi^2 (engines without
+// thermal states ahead of the points only: with them the likelihood walks the epoch-major copy, epochs_loop);
+// MODE 1: y_fit -> out0[row][orig];  MODE 2: T, R_bb -> out0, out1.
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM, int KPRE_POINTWISE = 0>
 __device__ inline double points_loop(const DevProblem& pb, int part, size_t row, const double* __restrict__ p,
                                      const double* __restrict__ c, const double2* __restrict__ th_base, int e_off,
                                      const double2* tbase, const FiltDesc* fdesc, const ExpTab et,
                                      double* __restrict__ out0, double* __restrict__ out1, int tid = threadIdx.x,
                                      int itab_at = -1) {
+    static_assert(!(THERM && MODE == 0), "the likelihood of an engine with thermal states is epochs_loop's");
     double term = 0.;  // `tid`: this thread's index among the kBlock threads that walk the part
     const int p0 = part_entry(pb.part_start, part), p1 = part_entry(pb.part_start, part + 1);  // this part's points
     // chunks whose operands are fetched together, before any band sum starts (fewer when the thermal state is computed
@@ -335,31 +635,6 @@ __device__ inline double points_loop(const DevProblem& pb, int part, size_t row,
                 const double2 yd = pb.pt_yd[i];   // (y, 1/dy), or (y, dy) when sigma is fitted
                 yv[u] = yd.x;
                 idy[u] = yd.y;
-            }
-        }
-        if (kPre % 2 == 0 && THERM && MODE == 0 && VARIANT != 0) {
-            // Interpolated points in PAIRS, where every lane of the wave has all its points of this round and all of
-            // them are inside their interpolants (the per-wave choice point_model makes point by point, for all of
-            // them here): power-law models without a per-point factor.  Same arithmetic in the same order as the
-            // general code below.
-            if (pb.use_itab && pb.itab_uniform && !pb.use_sigma && (pb.model == kShockCooling || pb.model == kShockCooling2)) {
-                bool general = false;
-#pragma unroll
-                for (int u = 0; u < kPre; ++u) general = general || idx[u] < 0 || __double2hiint(th[u].x) < 0;
-                if (__builtin_amdgcn_ballot_w64(general) == 0) {
-#pragma unroll
-                    for (int u = 0; u < kPre; u += 2) {
-                        double L0, L1;
-                        interp_log_band_sum2(pb, itab_at, filt[u] * pb.itab_m * 8, filt[u + 1] * pb.itab_m * 8, th[u].x,
-                                             th[u + 1].x, L0, L1);
-                        const double y0 = exp_scaled<false>((L0 + th[u].y) * kInvLn2N, et);
-                        const double y1 = exp_scaled<false>((L1 + th[u + 1].y) * kInvLn2N, et);
-                        const double q0 = (yv[u] - y0) * idy[u], q1 = (yv[u + 1] - y1) * idy[u + 1];
-                        term = fma(q0, q0, term);
-                        term = fma(q1, q1, term);
-                    }
-                    continue;
-                }
             }
         }
 #pragma unroll
@@ -440,10 +715,17 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     // byte offset of the staged interpolants in the dynamic LDS (behind the tables and descriptors), or -1
     const int itab_at = (LDS_TAB && pb.n_itab_lds > 0)
                             ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
-    const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
-        pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
-        tbase, fdesc, ExpTab{exptab}, out0, out1, threadIdx.x, itab_at);
-    if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * part_stride(pb) + part);
+    if constexpr (MODE == 0 && THERM) {
+        // (the thermal states are the lanes' own: k_thermal is not launched for the likelihood)
+        const double term = epochs_loop<VARIANT, LDS_TAB>(pb, part, P + (size_t)w * pb.n_dim, c, tbase, fdesc, ExpTab{exptab},
+                                                          threadIdx.x, itab_at);
+        store_part_sum(term, red, out0 + (size_t)w * part_stride(pb) + part);
+    } else {
+        const double term = points_loop<VARIANT, MODE, LDS_TAB, THERM>(
+            pb, part, (size_t)(w - w_lo), P + (size_t)w * pb.n_dim, c, THERM ? therm + (size_t)w * pb.n_epochs : nullptr, 0,
+            tbase, fdesc, ExpTab{exptab}, out0, out1, threadIdx.x, itab_at);
+        if (MODE == 0) store_part_sum(term, red, out0 + (size_t)w * part_stride(pb) + part);
+    }
 }
 
 template <int VARIANT, int MODE, bool LDS_TAB, bool THERM>
@@ -859,73 +1141,32 @@ __device__ inline void step_serial(const DevProblem& pb, const DevSampler& sm, i
     }
 }
 
-// One workgroup per (proposal slot i, epoch chunk): wave 0 commits half-step g - 1 for slot i (chunk 0 only) and draws
-// slot i of half-step g COOPERATIVELY -- the latency chain of a single thread (three accept tests with dependent
-// loads, then the logarithms of the proposal) is spread over lanes that run the same code on different data:
+// One 64-thread workgroup per proposal slot i: it commits half-step g - 1 for slot i and draws slot i of half-step g
+// COOPERATIVELY -- the latency chain of a single thread (three accept tests with dependent loads, then the logarithms of
+// the proposal) is spread over lanes that run the same code on different data:
 //   lanes 0..2: accept test of {previous slot i, own walker, partner walker}, with every load that does not depend
 //   on the outcome issued up front (both candidate rows included);  lanes 0..n_par-1: ln of the proposal's parameters.
-// Every lane ends with the same proposal (bitwise); lane 0 of the chunk-0 workgroup publishes it.  Then all 256
-// threads evaluate the thermal state of their epochs for the proposal (slots in [lo, hi) only: other ranks' shards).
+// Every lane ends with the same proposal (bitwise); lane 0 publishes it, with the coefficients and the log-prior of the
+// slots in [lo, hi) (this rank's shard) for the likelihood launch behind it (k_points: thermal states are its own).
 // ND > 0: the walker dimension is a compile-time constant (loops over parameters unroll with exact trip counts and
 // the per-parameter arrays live in registers); ND == 0: any dimension up to kMaxDim.
 template <int ND>
-__device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int bid, int have_prev,
-                                 long long prev_row, int have_next, const DrawRec* __restrict__ draws,
-                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi, int n_echunks,
-                                 int do_thermal, double* __restrict__ coef, double* __restrict__ lprior,
-                                 double2* __restrict__ therm) {
+__device__ inline void step_body(const DevProblem& pb, const DevSampler& sm, int i, int have_prev, long long prev_row,
+                                 int have_next, const DrawRec* __restrict__ draws, const DrawRec* __restrict__ prev_draws,
+                                 long long g, int lo, int hi, double* __restrict__ coef, double* __restrict__ lprior) {
     __shared__ double sc[kNCoef + 1];
-    // Workgroup -> work item.  With thermal states the shard's slots come first, n_echunks workgroups each; every
-    // other slot (another rank's: commit + light proposal, wave-0 work only) gets ONE WAVE of the workgroups after
-    // them, so a rank with a small shard of a large ensemble does not pay a workgroup per foreign slot.
-    int i, ec, lane;
-    const int own_groups = do_thermal ? (hi - lo) * n_echunks : 0;
-    if (do_thermal && bid >= own_groups) {
-        const int k = (bid - own_groups) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
-        i = k < lo ? k : k + (hi - lo);
-        ec = 0;
-        lane = threadIdx.x & 63;
-        if (i >= sm.n_half) return;
-    } else if (do_thermal) {
-        i = lo + bid / n_echunks;
-        ec = bid % n_echunks;
-        lane = threadIdx.x;
-    } else {
-        i = bid;
-        ec = 0;
-        lane = threadIdx.x;
-    }
     const bool mine = i >= lo && i < hi;       // this rank evaluates the likelihood of slot i
-    const bool in_shard = do_thermal && mine;
-    const int ep = ec * kBlock + lane;
-    const double t_ep = (in_shard && ep < pb.n_epochs) ? pb.epoch_t[ep] : 0.;  // issued before the serial section
-    if (lane < 64)
-        step_serial<ND>(pb, sm, i, ec == 0, lane, have_prev, prev_row, have_next, draws, prev_draws, g, mine, sc, nullptr,
+    if (threadIdx.x < 64)
+        step_serial<ND>(pb, sm, i, true, threadIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, mine, sc, nullptr,
                         coef, lprior);
-    if (!have_next || !in_shard) return;
-    __syncthreads();
-    if (sc[kNCoef] == -INFINITY) return;  // prior excludes the proposal: likelihood skipped
-    // a workgroup covers kBlock epochs with blockDim.x threads (64-thread workgroups when there are few epochs)
-    const int ep_end = min((ec + 1) * kBlock, pb.n_epochs);
-    for (int e2 = ep; e2 < ep_end; e2 += blockDim.x) {
-        double T, invT, pref;
-        if (pb.use_itab && pb.variant != 0)
-            thermal_state_log(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], invT, pref, ExpTab{pb.exp2tab});
-        else
-            thermal_state(pb, sc, e2 == ep ? t_ep : pb.epoch_t[e2], T, invT, pref);
-        therm[(size_t)i * pb.n_epochs + e2] = make_double2(invT, pref);
-    }
 }
 
 template <int ND>
-__global__ __launch_bounds__(kBlock) void k_step(const DevProblem pb, const DevSampler sm, int have_prev,
-                                                 long long prev_row, int have_next,
-                                                 const DrawRec* __restrict__ draws,
-                                                 const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
-                                                 int n_echunks, int do_thermal, double* __restrict__ coef,
-                                                 double* __restrict__ lprior, double2* __restrict__ therm) {
-    step_body<ND>(pb, sm, blockIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, lo, hi, n_echunks, do_thermal,
-              coef, lprior, therm);
+__global__ __launch_bounds__(64) void k_step(const DevProblem pb, const DevSampler sm, int have_prev, long long prev_row,
+                                             int have_next, const DrawRec* __restrict__ draws,
+                                             const DrawRec* __restrict__ prev_draws, long long g, int lo, int hi,
+                                             double* __restrict__ coef, double* __restrict__ lprior) {
+    step_body<ND>(pb, sm, blockIdx.x, have_prev, prev_row, have_next, draws, prev_draws, g, lo, hi, coef, lprior);
 }
 
 // ---- single-GPU fit: the whole half-step in ONE launch ---------------------------------------------------------------
@@ -961,7 +1202,6 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
                             ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);
     double* sq = sc + kNCoef + 2;
-    double2* lth = reinterpret_cast<double2*>(sc + kFusedScratch);
     const int tid = threadIdx.x;
     // Multi-GPU: this rank evaluates the slots [lo, hi) only.  Every other slot (commit + light proposal, no
     // likelihood) takes one WAVE of the workgroups launched behind the shard's own.
@@ -987,38 +1227,16 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
 #pragma unroll
     for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
     if (reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, cs[6], tid, kBlock);
-    const int e0 = THERM ? part_entry(pb.part_ep0, part) : 0;
-    if (THERM) {
-        const int e1 = part_entry(pb.part_ep0, part + 1);
-        for (int e = e0 + tid; e < e1; e += kBlock) {
-            double T, invT, pref;
-            if (VARIANT != 0 && pb.use_itab)
-                thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
-            else
-                thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
-            lth[e - e0] = make_double2(invT, pref);
-        }
-    }
-    if (THERM || reddened) __syncthreads();
-    const double term = points_loop<VARIANT, 0, true, THERM>(pb, part, 0, sq, cs, lth, e0, ltab, fdesc, ExpTab{exptab},
-                                                             nullptr, nullptr, threadIdx.x, itab_at);
+    if (reddened) __syncthreads();
+    double term;
+    if constexpr (THERM)
+        term = epochs_loop<VARIANT, true>(pb, part, sq, cs, ltab, fdesc, ExpTab{exptab}, tid, itab_at);
+    else
+        term = points_loop<VARIANT, 0, true, false>(pb, part, 0, sq, cs, nullptr, 0, ltab, fdesc, ExpTab{exptab}, nullptr,
+                                                    nullptr, tid, itab_at);
     const double psum = store_part_sum(term, red, sm.part2[g & 1] + (size_t)i * part_stride(pb) + part);
     if (sm.n_peers > 0 && tid == 0) mbox_post(sm, g, i, part, part_stride(pb), psum);  // straight into every rank's mailbox
 }
-
-// Diagnostic build only (-DLCF_STAMPS, tools/debug/make_stamp_build.py; never shipped): s_memtime stamps of the first 64
-// workgroups of k_solo, written by the first lane of wave `W` into a buffer nothing else reads.
-#ifdef LCF_STAMPS
-__device__ unsigned long long g_stamps[64 * 16];
-#define LCF_STAMP(W, k)                                                                                        \
-    do {                                                                                                       \
-        unsigned long long t_;                                                                                 \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
-        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) g_stamps[blockIdx.x * 16 + (k)] = t_;                  \
-    } while (0)
-#else
-#define LCF_STAMP(W, k) do {} while (0)
-#endif
 
 // ---- row boards: tagged words in uncached memory ------------------------------------------------------------------
 // One float64 = two 8-byte granules {32 data bits, 32-bit tag}, tag = half-step after which the row holds + 1 (the LL
@@ -1130,32 +1348,57 @@ __global__ void k_board_collect(const DevSampler sm, long long G, long long row,
 // BOARD: the rows come from this rank's row board instead of X / LP -- lanes 0 .. nd-1 poll the partner's position,
 // lanes 16 .. 16+nd+1 the walker's position, log-posterior and acceptance count (left in sx[kMaxDim + 1]), each for the
 // version the draw record names -- and are handed round by shuffles; everything after that is the same arithmetic.
+// What the head reads from memory, requested first (head_fetch) and used later (proposal_head): the kernels put their
+// other early loads between the two, so that nothing of theirs queues in front of these.
+template <int ND>
+struct HeadRows {
+    static constexpr int kD = ND > 0 ? ND : kMaxDim;
+    double x[kD], cj[kD];   // the walker's position, the partner's
+    double lp_i, got;       // the walker's log-posterior; BOARD: this lane's word of the rows
+    PriorDev prior;         // lane d: the prior of parameter d
+};
+
 template <int ND, bool BOARD = false>
-__device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
-                                              double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx,
-                                              long long G = 0, long long g_run0 = 0) {
+__device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
+                                           HeadRows<ND>& h, long long G = 0, long long g_run0 = 0) {
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
-    PriorDev my_prior{0, 0, 0., 0., 0., 1.};
-    if (lane < pb.n_dim && pb.has_priors) my_prior = pb.priors[lane];
     const double* xs = sm.X + (size_t)dr.wid * nd;
     const double* cs_ = sm.X + (size_t)dr.pid * nd;
-    double x[kD], q[kMaxDim], lq[kMaxDim];
-#pragma unroll
-    for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
-    double got = 0.;
+    h.got = 0.;
     if (BOARD) {
         const bool own = lane >= 16;
         const int col = own ? lane - 16 : lane;
         if (own ? col <= nd + 1 : col < nd)
-            got = board_take(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
+            h.got = board_take(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
     }
-    const double lp_i = BOARD ? lane_value(got, 16 + nd) : sm.LP[dr.wid];
+    h.lp_i = BOARD ? lane_value(h.got, 16 + nd) : sm.LP[dr.wid];
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+        h.x[d] = d < nd ? (BOARD ? lane_value(h.got, 16 + d) : xs[d]) : 0.;
+        h.cj[d] = d < nd ? (BOARD ? lane_value(h.got, d) : cs_[d]) : 0.;
+    }
+    h.prior = PriorDev{0, 0, 0., 0., 0., 1.};
+    if (lane < pb.n_dim && pb.has_priors) h.prior = pb.priors[lane];
+}
+
+template <int ND, bool BOARD = false, int MODEL = 0>
+__device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
+                                              double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx,
+                                              const HeadRows<ND>& h) {
+    constexpr int kD = ND > 0 ? ND : kMaxDim;
+    const int nd = ND > 0 ? ND : sm.n_dim;
+    const PriorDev my_prior = h.prior;
+    double x[kD], q[kMaxDim], lq[kMaxDim];
+#pragma unroll
+    for (int d = 0; d < kMaxDim; ++d) q[d] = lq[d] = 0.;
+    const double got = h.got;
+    const double lp_i = h.lp_i;
     double arg = 1.;
 #pragma unroll
     for (int d = 0; d < kD; ++d) {
-        x[d] = d < nd ? (BOARD ? lane_value(got, 16 + d) : xs[d]) : 0.;
-        const double cj = d < nd ? (BOARD ? lane_value(got, d) : cs_[d]) : 0.;
+        x[d] = h.x[d];
+        const double cj = h.cj[d];
         q[d] = d < nd ? cj - (cj - x[d]) * dr.z : 0.;   // emcee: c_j - (c_j - x_i) z
         if (lane == d && d < pb.n_par) arg = q[d];
     }
@@ -1168,7 +1411,7 @@ __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSam
     for (int d = 0; d < kD; ++d) lq[d] = lane_value(lg, d);
     LCF_STAMP(0, 3);
     double c[kNCoef];
-    walker_coefficients(pb, q, lq, c, pb.use_itab != 0);
+    walker_coefficients<MODEL>(pb, q, lq, c, MODEL ? true : pb.use_itab != 0);
     LCF_STAMP(0, 4);
     double lpr = 0.;
     if (pb.has_priors) {
@@ -1218,11 +1461,19 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // threads take parts j, j + 2 one after the other.  512 threads either way, so that two workgroups share a CU and one's
 // serial head overlaps the other's points (1024-thread workgroups for four parts, one per CU: companion fit 1.26e7
 // walker-steps/s; this way 1.41e7).
-template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false>
+// MODEL > 0: the kernel is compiled for that one model and for what the benchmark shapes have in common -- dense columns,
+// interpolants proved from their first interval, no fitted sigma -- so that the other models' arithmetic is not in its
+// instruction stream (a launch streams its code from L2 into cold instruction caches: 89 KiB of kernel, ~28 KiB of
+// them executed, cost the generic kernel a third of its time).
+template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false, int MODEL = 0>
 __global__ __launch_bounds__(kBlock * 2, LCF_WAVES)
-void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
+void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
             const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // The problem is read through a constant-address-space pointer: scalar loads where a field is used, instead of
+    // 700 bytes of kernel arguments preloaded into (and spilled from) scalar registers.
+    typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
+    const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
     double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
@@ -1233,13 +1484,15 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     double* sq = sc + kNCoef + 2;                                           // the proposal
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
     int* sctl = reinterpret_cast<int*>(sc + kSoloScratch + 2);              // BOARD: [0] = 1: the launch is aborted
-    double2* lth = reinterpret_cast<double2*>(sc + kSoloScratch + 4);
     constexpr int kThreads = kBlock * 2;
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const int tid = threadIdx.x, i = blockIdx.x + (BOARD ? slot_lo : 0);
-    const bool reddened = pb.model == kShockCooling3;
+    const bool reddened = !MODEL && pb.model == kShockCooling3;
     LCF_STAMP(0, 0);
+#ifdef LCF_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) g_wall[((G & 1) * 1024 + blockIdx.x) * 2] = wall_clock64();
+#endif
     const DrawRec dr = draws[i];     // wave-uniform
     if (BOARD && blockIdx.x == 0 && tid < sm.n_board_ranks)
         // This launch runs, so every launch in front of it in the stream has finished: tell every rank that this rank
@@ -1248,9 +1501,21 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
                            __HIP_MEMORY_SCOPE_SYSTEM);
     if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
     LCF_STAMP(0, 1);
+    // the operands of this thread's first column (of the first part its half of the workgroup walks): requested now,
+    // needed behind the barrier
+    // (the head's own loads go first; the other waves' streams -- tables, photometry: 80 KiB per workgroup through the
+    // same path -- start once they are out: rows + proposal 3.8 k cycles with everything requested at once, 2.1 k alone)
+    // (model-specialised kernels only: the generic ones need the registers for the point-by-point path)
+    constexpr bool kFetch = MODEL != 0;
+    ColumnOperands first_col;
     if (tid < 64) {
-        proposal_head<ND, BOARD>(pb, sm, dr, tid, sc, sq, sx, G, g_run0);
+        HeadRows<ND> rows;
+        head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0);
+        if (kFetch) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
+        proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
     } else {
+        if (LCF_HEAD_START > 0) __builtin_amdgcn_s_sleep(LCF_HEAD_START);
+        if (kFetch) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
         // (a hint only: nothing depends on the value or on the placement).
@@ -1291,52 +1556,65 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
     const double lpr = sc[kNCoef];
     double term = 0.;
     const bool excluded = lpr == -INFINITY;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
-    if (!excluded) {
+    // The benchmark shape in a MODEL-specialised kernel: every lane has ONE column, fetched ahead of the head
+    // (lean_column); anything else -- more columns than lanes, another filter count, interpolants outside LDS, a wave with
+    // a state outside the interpolants -- goes through epochs_loop / the cold path, same numbers.
+    bool lean = false;
+    if (MODEL != 0 && NPARTS <= 2 && !excluded) {
+        const int part = __builtin_amdgcn_readfirstlane(tid / kBlock), ltid = tid % kBlock;
+        const int c0 = part_entry(pb.part_col0, part), c1 = part_entry(pb.part_col0, part + 1);
+        lean = first_col.have_o && itab_at >= 0 && c1 - c0 <= kBlock && part < pb.n_parts;   // (wave-uniform)
+        if (lean) {
+            LCF_STAMP(0, 7);
+            double acc = 0.;
+            if (c0 + (ltid & ~63) < c1) {   // (a virtual wave without columns adds nothing)
+                const bool live = c0 + ltid < c1;
+                if (!lean_column<MODEL>(pb, sc, first_col, ExpTab{exptab}, itab_at, acc))
+                    acc = cold_column_with_state<VARIANT, MODEL>(pbp, sc, sq, first_col.t, min(c0 + ltid, c1 - 1), live);
+                term = live ? acc : 0.;     // (lanes beyond the part repeated its last column)
+            }
+            LCF_STAMP(0, 8);
+            LCF_STAMP(1, 12);
+            const double ws = wave_sum(term);
+            if ((tid & 63) == 0) red[tid >> 6] = ws;
+        }
+    }
+    if (!excluded && !lean) {
         double cs[kNCoef];
 #pragma unroll
         for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
         if (reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, cs[6], tid, kThreads);
+        // threads [256 j, 256 j + 256) are the virtual threads of part j (NPARTS = 4: then of part j + 2, ...): each lane
+        // computes the thermal state of its column and walks the column's points (epochs_loop)
         const int part = tid / kBlock, ltid = tid % kBlock;
-        if (THERM) {
-            // thread (part, ltid) computes the epochs a k_fused workgroup of that part would: same values, all in LDS
-            // (NPARTS = 4: of parts `part` and `part + 2`)
-            const int e0 = part_entry(pb.part_ep0, part), e1 = part_entry(pb.part_ep0, part + 1);
-#pragma unroll 1
-            for (int e = e0 + ltid; e < e1; e += kBlock) {
-                double T, invT, pref;
-                if (pb.use_itab)
-                    thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
-                else
-                    thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
-                lth[e] = make_double2(invT, pref);
-            }
-            if (NPARTS > 2) {
-                const int f0 = part_entry(pb.part_ep0, part + 2), f1 = part + 2 < pb.n_parts ? part_entry(pb.part_ep0, part + 3) : f0;
-#pragma unroll 1
-                for (int e = f0 + ltid; e < f1; e += kBlock) {
-                    double T, invT, pref;
-                    if (pb.use_itab)
-                        thermal_state_log(pb, cs, pb.epoch_t[e], invT, pref, ExpTab{exptab});
-                    else
-                        thermal_state(pb, cs, pb.epoch_t[e], T, invT, pref);
-                    lth[e] = make_double2(invT, pref);
-                }
-            }
-        }
-        if (THERM || reddened) __syncthreads();
+        if (reddened) __syncthreads();
         LCF_STAMP(0, 7);
         if (NPARTS > 2) {
 #pragma unroll 1
             for (int pp = part; pp < pb.n_parts; pp += 2) {
-                term = points_loop<VARIANT, 0, true, THERM, 1>(pb, pp, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
-                                                               nullptr, nullptr, ltid, itab_at);
+                term = epochs_loop<VARIANT, true, kFetch, MODEL, true>(pb, pp, sq, cs, ltab, fdesc, ExpTab{exptab}, ltid, itab_at,
+                                                                       first_col, pp == part, pbp, sc);
                 const double ws = wave_sum(term);
                 if ((tid & 63) == 0) red[4 * pp + (ltid >> 6)] = ws;
             }
         } else {
+#ifdef LCF_TWICE   // diagnostic: the column phase twice through the SAME code (second pass: warm instruction cache)
+            {
+                int reps_;
+                asm volatile("s_mov_b32 %0, 2" : "=s"(reps_));
+#pragma unroll 1
+                for (int rep = 0; rep < reps_; ++rep) {
+                    if (part < pb.n_parts)
+                        term = epochs_loop<VARIANT, true, kFetch, MODEL, true>(pb, part, sq, cs, ltab, fdesc, ExpTab{exptab}, ltid,
+                                                                               itab_at, first_col, true, pbp, sc);
+                    if (rep == 0) LCF_STAMP(0, 7);
+                }
+            }
+#else
             if (part < pb.n_parts)
-                term = points_loop<VARIANT, 0, true, THERM, 1>(pb, part, 0, sq, cs, lth, 0, ltab, fdesc, ExpTab{exptab},
-                                                               nullptr, nullptr, ltid, itab_at);
+                term = epochs_loop<VARIANT, true, kFetch, MODEL, true>(pb, part, sq, cs, ltab, fdesc, ExpTab{exptab}, ltid, itab_at,
+                                                                       first_col, true, pbp, sc);
+#endif
             LCF_STAMP(0, 8);
             LCF_STAMP(1, 12);
             const double ws = wave_sum(term);
@@ -1401,6 +1679,9 @@ void k_solo(const DevProblem pb, const DevSampler sm, long long row, const DrawR
         sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = ok ? nlp : lp_i;
     }
     LCF_STAMP(0, 10);
+#ifdef LCF_STAMPS
+    if (blockIdx.x < 1024) g_wall[((G & 1) * 1024 + blockIdx.x) * 2 + 1] = wall_clock64();
+#endif
 }
 
 // State of the sampler as 8-byte words into (mapped, pinned) host memory: [error flag | X | LP | n_accepted].
@@ -1421,7 +1702,6 @@ struct MultiItem {
     long long blk_first, blk_steps; // steps in block 0 / in every later block
     double* coef;
     double* lprior;
-    double2* therm;
 };
 
 // Draw records of a transient's half-step `rel` of the run (the host keeps that block resident).
@@ -1433,16 +1713,14 @@ __device__ inline const DrawRec* item_rows(const MultiItem& it, long long rel) {
 }
 
 template <int ND>
-__global__ __launch_bounds__(kBlock) void k_step_multi(const MultiItem* __restrict__ items, int have_prev,
-                                                       long long prev_row, int have_next, long long rel,
-                                                       long long g, int thermal) {
+__global__ __launch_bounds__(64) void k_step_multi(const MultiItem* __restrict__ items, int have_prev, long long prev_row,
+                                                   int have_next, long long rel, long long g) {
     const MultiItem& it = items[blockIdx.y];
     const int nh = it.sm.n_half;
-    const int nec = thermal ? (it.pb.n_epochs + kBlock - 1) / kBlock : 1;
-    if ((int)blockIdx.x >= nh * nec) return;
+    if ((int)blockIdx.x >= nh) return;
     step_body<ND>(it.pb, it.sm, blockIdx.x, have_prev, prev_row, have_next,
-              have_next ? item_rows(it, rel) : nullptr, have_prev ? item_rows(it, rel - 1) : nullptr,
-              g, 0, nh, nec, thermal, it.coef, it.lprior, it.therm);
+                  have_next ? item_rows(it, rel) : nullptr, have_prev ? item_rows(it, rel - 1) : nullptr,
+                  g, 0, nh, it.coef, it.lprior);
 }
 
 template <int VARIANT, bool LDS_TAB, bool THERM>
@@ -1450,7 +1728,7 @@ __global__ __launch_bounds__(kBlock) void k_points_multi(const MultiItem* __rest
     const MultiItem& it = items[blockIdx.y];
     const int nh = it.sm.n_half;
     if ((int)blockIdx.x >= nh * it.pb.n_parts) return;
-    points_body<VARIANT, 0, LDS_TAB, THERM>(it.pb, blockIdx.x, 0, nh, it.sm.Q[parity], it.coef, it.lprior, it.therm,
+    points_body<VARIANT, 0, LDS_TAB, THERM>(it.pb, blockIdx.x, 0, nh, it.sm.Q[parity], it.coef, it.lprior, nullptr,
                                             it.sm.part2[parity], nullptr);
 }
 
@@ -1472,7 +1750,7 @@ constexpr int kPopMaxParts = 4;
 #endif
 // GROUP = proposals (= waves) per workgroup: 4, or 8 with two proposals' points walked side by side (threads
 // [0, 256) and [256, 512), each half exactly as a k_points workgroup).
-template <int ND, int VARIANT, int GROUP>
+template <int ND, int VARIANT, int GROUP, int MODEL = 0>
 __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiItem* __restrict__ items, long long rel) {
     extern __shared__ __align__(16) unsigned char smem[];
     typedef const MultiItem __attribute__((address_space(4)))* ItemPtr;
@@ -1480,7 +1758,7 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
     const MultiItem& it = *(const MultiItem*)itp;
     const DevProblem& pb = it.pb;
     const DevSampler& sm = it.sm;
-    constexpr int kThreads = 64 * GROUP, kSide = GROUP / 4;
+    constexpr int kThreads = 64 * GROUP;
     const int nh = sm.n_half, slot0 = blockIdx.x * GROUP;
     if (slot0 >= nh) return;
     double* exptab = reinterpret_cast<double*>(smem);
@@ -1490,11 +1768,9 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
                             ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     double* scratch = reinterpret_cast<double*>(ltab + pb.stage_d2);       // [GROUP][kPopScratch]
     double* red = scratch + GROUP * kPopScratch;                             // [GROUP][4 * kPopMaxParts] wave sums
-    double2* lth = reinterpret_cast<double2*>(red + GROUP * 4 * kPopMaxParts);  // [GROUP][n_epochs]
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_ep = pb.n_epochs;
     stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid, kThreads);
     {
         // ---- the serial heads, one per wave, side by side
@@ -1505,7 +1781,11 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
         DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0, 0};
         if (slot < nh) dr = item_rows(it, rel)[slot];     // wave-uniform
         const bool active = dr.wid >= 0;  // (an odd ensemble's smaller colour leaves its last slot empty)
-        if (active) proposal_head<ND>(pb, sm, dr, lane, sc, sq, sx);
+        if (active) {
+            HeadRows<ND> rows;
+            head_fetch<ND>(pb, sm, dr, lane, rows);
+            proposal_head<ND, false, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
+        }
         if (lane == 0) {
             if (!active) sc[kNCoef] = -INFINITY;
             sx[kMaxDim + 1] = dr.zl;
@@ -1514,34 +1794,27 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
         }
     }
     __syncthreads();
-    // ---- thermal states of all proposals, one (proposal, epoch) pair per thread and round
-    for (int idx = tid; idx < GROUP * n_ep; idx += kThreads) {
-        const int w = idx / n_ep, e = idx - w * n_ep;
-        const double* sc = scratch + w * kPopScratch;
-        if (sc[kNCoef] == -INFINITY) continue;   // the prior excludes the proposal (or the slot is empty)
-        double T, invT, pref;
-        if (pb.use_itab)
-            thermal_state_log(pb, sc, pb.epoch_t[e], invT, pref, ExpTab{exptab});
-        else
-            thermal_state(pb, sc, pb.epoch_t[e], T, invT, pref);
-        lth[(size_t)w * n_ep + e] = make_double2(invT, pref);
-    }
-    __syncthreads();
-    // ---- the points, proposal by proposal (kSide of them side by side)
-    const int side = wave / 4, ltid = tid & (kBlock - 1);
+    // ---- thermal states + points: the unit of work is a VIRTUAL WAVE (proposal w, part, v) -- the 64 columns
+    // part_col0 + 64 v + lane (+ 256 m) of epochs_loop, exactly what wave v of a k_points workgroup for (w, part) walks, so a
+    // transient's chain is bitwise the one every other kernel produces.  The physical waves take the units round-robin,
+    // proposal fastest: with up to GROUP non-empty units per (part, v) every wave stays with one proposal.
+    {
+        const int n_units = GROUP * pb.n_parts * 4;
 #pragma unroll 1
-    for (int w = side; w < GROUP; w += kSide) {
-        const double* sc = scratch + w * kPopScratch;
-        if (sc[kNCoef] == -INFINITY) continue;   // (uniform within each side: its threads read the same word)
-        double cs[kNCoef];
+        for (int u = wave; u < n_units; u += GROUP) {
+            const int w = u % GROUP, pv = u / GROUP, part = pv >> 2, v = pv & 3;
+            const double* sc = scratch + w * kPopScratch;
+            double ws = 0.;
+            const bool empty = part_entry(pb.part_col0, part) + 64 * v >= part_entry(pb.part_col0, part + 1);
+            if (!empty && sc[kNCoef] != -INFINITY) {   // (wave-uniform)
+                double cs[kNCoef];
 #pragma unroll
-        for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
-#pragma unroll 1
-        for (int part = 0; part < pb.n_parts; ++part) {
-            const double term = points_loop<VARIANT, 0, true, true, 1>(pb, part, 0, sc + kNCoef + 2, cs, lth + (size_t)w * n_ep, 0,
-                                                                       ltab, fdesc, ExpTab{exptab}, nullptr, nullptr, ltid, itab_at);
-            const double ws = wave_sum(term);
-            if (lane == 0) red[(w * kPopMaxParts + part) * 4 + (wave & 3)] = ws;
+                for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
+                const double term = epochs_loop<VARIANT, true, false, MODEL>(pb, part, sc + kNCoef + 2, cs, ltab, fdesc, ExpTab{exptab},
+                                                               64 * v + lane, itab_at);
+                ws = wave_sum(term);
+            }
+            if (lane == 0) red[(w * kPopMaxParts + part) * 4 + v] = ws;
         }
     }
     __syncthreads();
@@ -1608,7 +1881,15 @@ struct lcf_engine {
     int* d_ctab_off = nullptr;  // per filter: (offset, count) of the compressed table
     double* d_ctmin = nullptr;
     bool have_ctab = false, have_itab = false;
-    int max_part_epochs = 0;  // most distinct epochs in one part (LDS need of the fused sampler kernel)
+    DevProblem* d_dp = nullptr;  // `dp` in device memory, for the kernels that read it through a pointer
+    lcf_status sync_dp() {       // after every change of `dp`
+        if (!d_dp) {
+            LCF_HIP(hipMalloc((void**)&d_dp, sizeof(DevProblem)));
+            owned.push_back(d_dp);
+        }
+        LCF_HIP(hipMemcpy(d_dp, &dp, sizeof(DevProblem), hipMemcpyHostToDevice));
+        return LCF_OK;
+    }
     // workspace for n walkers
     int64_t cap = 0;
     double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
@@ -1661,14 +1942,13 @@ struct lcf_engine {
 
 namespace {
 
-// More than the default 64 KiB of dynamic LDS must be granted per kernel function, once.
+// More than the default 64 KiB of dynamic LDS must be granted per kernel function -- and per DEVICE: the attribute
+// belongs to the current device's copy of the function, so it is set before every such launch (cheap next to one; a
+// per-process flag would leave the second device of a process without it).
 template <class K>
 inline void allow_lds(K kernel, size_t bytes) {
-    static bool raised = false;  // one flag per kernel type = per instantiation
-    if (bytes > 64 * 1024 && !raised) {
+    if (bytes > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
 }
 
 template <int VARIANT, int MODE>
@@ -1691,7 +1971,7 @@ template <int MODE>
 void launch_points(const lcf_engine* e, int w_lo, int n, const double* dP, const double* coef, const double* lprior,
                    double2* therm, double* out0, double* out1, hipStream_t st, bool do_thermal = true) {
     const DevProblem& pb = e->dp;
-    if (pb.use_therm && do_thermal) {
+    if (pb.use_therm && do_thermal && MODE == 1) {   // (the likelihood's lanes compute their own: epochs_loop)
         const long long total = (long long)n * pb.n_epochs;
         hipLaunchKernelGGL(k_thermal, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, pb, w_lo, n,
                            coef, lprior, MODE == 0 ? 1 : 0, therm, (MODE != 2 && pb.variant != 0 && pb.use_itab) ? 1 : 0);
@@ -1814,12 +2094,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         epochs.erase(std::unique(epochs.begin(), epochs.end()), epochs.end());
     }
     const int n_chunks_all = std::max(1, (N + kBlock - 1) / kBlock);
-    // workgroups per walker: every one repeats the prologue (table staging; in the fused sampler kernel also the
-    // serial part of the half-step), so few of them -- two up to 16 chunks, then one per 8 chunks (measured on the
-    // 1024-walker, 3000-point fit: 2 parts 52 us/step, 4 parts 61, 8 parts 83)
-    int n_parts = std::min(n_chunks_all, std::min(kMaxParts, std::max(2, (n_chunks_all + 7) / 8)));
-    if (const char* env = std::getenv("LCF_PARTS"))
-        n_parts = std::max(1, std::min(std::min(n_chunks_all, kMaxParts), std::atoi(env)));
     std::vector<int> order(N);
     std::iota(order.begin(), order.end(), 0);
     auto epoch_of = [&](int i) {
@@ -1828,17 +2102,77 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     std::vector<int> ep_of(N);
     for (int i = 0; i < N; ++i) ep_of[i] = epoch_of(i);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ep_of[a] < ep_of[b]; });
-    std::vector<int> part_start(kMaxParts + 1, N);
+    // Thermal states per (walker, observation time) ahead of the points.  With >= 2 points per distinct time that is
+    // sharing; without any (real multi-band photometry: every observation has its own time) it still is what puts a
+    // light curve on the fast path -- log-space states, interpolated band sums, k_solo.  LCF_SHARED_EPOCHS_ONLY=1
+    // restores the round-1 rule, sharing or nothing (read at every engine creation: the tests of the
+    // state-inside-the-point-loop kernels set it).
+    const bool shared_only = std::getenv("LCF_SHARED_EPOCHS_ONLY") != nullptr;
+    const bool sharing = 2 * (long long)epochs.size() <= N;
+    const bool epochs_ahead = all_finite_t && N > 0 && (sharing || !shared_only);
+    // ---- the epoch-major copy the likelihood walks (DevProblem::em_*): COLUMNS = an observation time with up to em_k of
+    // its points in filter order; an epoch with more points than that takes several columns (em_k = the most points of
+    // an epoch, but at most twice the mean, so that ragged photometry does not pad the arrays beyond ~3 N entries) ----
+    int em_k = 1, em_dense = 0;
+    std::vector<int> col_epoch, col_first;   // per column: its epoch, its first point in em_order
+    std::vector<int> em_order;               // points by (epoch, filter, caller's index)
+    std::vector<int> ep_col0;                // first column of every epoch (+ one past the last)
+    if (epochs_ahead) {
+        em_order = order;
+        std::stable_sort(em_order.begin(), em_order.end(), [&](int a, int b) {
+            return ep_of[a] != ep_of[b] ? ep_of[a] < ep_of[b] : pr->filt_idx[a] < pr->filt_idx[b];
+        });
+        const int n_ep = (int)epochs.size();
+        std::vector<int> cnt(n_ep, 0);
+        for (int i = 0; i < N; ++i) ++cnt[ep_of[i]];
+        const int kmax = *std::max_element(cnt.begin(), cnt.end());
+        em_k = std::min(kmax, std::max(2, (int)((2LL * N + n_ep - 1) / n_ep)));
+        ep_col0.assign(n_ep + 1, 0);
+        for (int e = 0, at = 0; e < n_ep; ++e) {
+            ep_col0[e] = (int)col_epoch.size();
+            for (int k = 0; k < cnt[e]; k += em_k) {
+                col_epoch.push_back(e);
+                col_first.push_back(at + k);
+            }
+            at += cnt[e];
+        }
+        ep_col0[n_ep] = (int)col_epoch.size();
+        em_dense = em_k == NF && (long long)n_ep * NF == N;
+        for (int i = 0; em_dense && i < N; ++i)   // every epoch holds filters 0 .. NF-1, one point each
+            if (pr->filt_idx[em_order[i]] != i % NF) em_dense = 0;
+    }
+    const int n_cols = (int)col_epoch.size();
+    // workgroups per walker ("parts"): every one repeats the prologue (table staging; in the fused sampler kernel also
+    // the serial part of the half-step), so few of them.  Epoch-major engines: a part is what 256 lanes walk, one
+    // column each and round -- one part per 256 columns; else two parts up to 16 chunks of points, then one per 8
+    // (measured on the 1024-walker, 3000-point fit in round 1: 2 parts 52 us/step, 4 parts 61, 8 parts 83)
+    int n_parts = std::min(n_chunks_all, std::min(kMaxParts, std::max(2, (n_chunks_all + 7) / 8)));
+    if (epochs_ahead) n_parts = std::min(kMaxParts, std::max(n_cols > 64 ? 2 : 1, (n_cols + kBlock - 1) / kBlock));
+    if (const char* env = std::getenv("LCF_PARTS"))
+        n_parts = std::max(1, std::min(std::min(epochs_ahead ? n_cols : n_chunks_all, kMaxParts), std::atoi(env)));
+    std::vector<int> part_start(kMaxParts + 1, N), part_col0(kMaxParts + 1, n_cols);
     part_start[0] = 0;
+    part_col0[0] = 0;
     {
         int made = 0;
-        for (int j = 1; j < n_parts; ++j) {  // boundary j: the first epoch change at or after the equal-count split
-            int b = (int)((long long)N * j / n_parts);
-            while (b < N && b > 0 && ep_of[order[b]] == ep_of[order[b - 1]]) ++b;
+        for (int j = 1; j < n_parts; ++j) {
+            int b;  // boundary j: the first epoch change at or after the equal split (of the columns / of the points)
+            if (epochs_ahead) {
+                int cb = (int)((long long)n_cols * j / n_parts);
+                while (cb < n_cols && cb > 0 && col_epoch[cb] == col_epoch[cb - 1]) ++cb;
+                b = cb < n_cols ? col_first[cb] : N;   // (`order` and em_order agree on where an epoch starts)
+                if (b > part_start[made] && b < N) part_col0[made + 1] = cb;
+            } else {
+                b = (int)((long long)N * j / n_parts);
+                while (b < N && b > 0 && ep_of[order[b]] == ep_of[order[b - 1]]) ++b;
+            }
             if (b > part_start[made] && b < N) part_start[++made] = b;
         }
         n_parts = made + 1;
-        for (int j = n_parts; j <= kMaxParts; ++j) part_start[j] = N;
+        for (int j = n_parts; j <= kMaxParts; ++j) {
+            part_start[j] = N;
+            part_col0[j] = n_cols;
+        }
     }
     for (int j = 0; j < n_parts; ++j)
         std::stable_sort(order.begin() + part_start[j], order.begin() + part_start[j + 1],
@@ -1970,7 +2304,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.n_parts = n_parts;
     dp.cpb = cpb;
     for (int j = 0; j <= kMaxParts; ++j) dp.part_start[j] = part_start[j];
-    e->max_part_epochs = 0;
     for (int j = 0; j <= kMaxParts; ++j)  // epochs were sorted, so a part's epoch range starts at its first point's
         dp.part_ep0[j] = (j < n_parts && part_start[j] < N && all_finite_t) ? ep_of[order[part_start[j]]]
                                                                               : (int)epochs.size();
@@ -1981,8 +2314,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
             for (int i = part_start[j]; i < part_start[j + 1]; ++i) lo = std::min(lo, hepoch[i]);
             dp.part_ep0[j] = lo;
         }
-        for (int j = 0; j < n_parts; ++j)
-            e->max_part_epochs = std::max(e->max_part_epochs, dp.part_ep0[j + 1] - dp.part_ep0[j]);
     }
     dp.n_tab = (int)htab.size();
     dp.n_filters = NF;
@@ -2004,17 +2335,11 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     if (dp.redden_slow) dp.n_lds_tab = 0;
     dp.tab_in_lds = dp.n_lds_tab > 0;
     dp.n_epochs = (int)epochs.size();
-    // Thermal states per (walker, epoch), ahead of the point loop.  With >= 2 points per distinct time that is sharing;
-    // without any (real multi-band photometry: every observation has its own time) it still is what puts a light curve
-    // on the fast path -- log-space states in LDS, interpolated band sums, k_solo: 27.8 -> 20.0 us per half-step at the
-    // configs[1] size (tools/debug/ragged_times.py).  LCF_SHARED_EPOCHS_ONLY=1 restores the round-1 rule, sharing or
-    // nothing (read at every engine creation: the tests of the state-inside-the-point-loop kernels set it).
-    const bool shared_only = std::getenv("LCF_SHARED_EPOCHS_ONLY") != nullptr;
-    // (without sharing only while a proposal's states fit beside the tables in LDS, 64 KiB = 4096 observations: beyond
-    // that the states would travel through memory, n_walkers x N x 16 bytes, for nothing)
-    const bool sharing = 2 * (long long)epochs.size() <= N;
-    const bool epochs_ahead = all_finite_t && N > 0 && (sharing || (!shared_only && epochs.size() <= 4096));
     dp.use_therm = epochs_ahead;
+    dp.em_k = em_k;
+    dp.em_cols = n_cols;
+    dp.em_dense = em_dense;
+    for (int j = 0; j <= kMaxParts; ++j) dp.part_col0[j] = part_col0[j];
     dp.variant = 1;
     dp.use_ctab = have_ctab ? 1 : 0;
     e->have_ctab = have_ctab;
@@ -2080,6 +2405,29 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         UP(hyd, dyd);
         dp.pt_yd = dyd;
     }
+    if (epochs_ahead) {   // the epoch-major copy: [em_k][n_cols], a column's points in filter order
+        std::vector<double> hct(n_cols);
+        std::vector<double2> hcyd((size_t)em_k * n_cols, make_double2(0., 0.));
+        std::vector<int> hcf((size_t)em_k * n_cols, -1);
+        for (int cidx = 0; cidx < n_cols; ++cidx) {
+            const int ep = col_epoch[cidx];
+            hct[cidx] = epochs[ep];
+            for (int k = 0; k < em_k; ++k) {
+                const int at = col_first[cidx] + k;
+                if (at >= N || ep_of[em_order[at]] != ep) break;
+                const int o = em_order[at];
+                hcyd[(size_t)k * n_cols + cidx] = make_double2(pr->y[o], pr->use_sigma ? pr->dy[o] : 1. / pr->dy[o]);
+                hcf[(size_t)k * n_cols + cidx] = pr->filt_idx[o];
+            }
+        }
+        double* dct;
+        double2* dcyd;
+        int* dcf;
+        UP(hct, dct); UP(hcyd, dcyd); UP(hcf, dcf);
+        dp.em_t = dct;
+        dp.em_yd = dcyd;
+        dp.em_filt = dcf;
+    }
     if (NF <= 64) {  // filter and epoch of a point in one word (epochs < 2^26 = the most points an engine takes)
         std::vector<int> hfe(N);
         for (int i = 0; i < N; ++i) hfe[i] = (int)((unsigned int)hfilt[i] | ((unsigned int)hepoch[i] << 6));
@@ -2120,6 +2468,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_filt = dfilt; dp.pt_orig = dorig;
     dp.tab = dtab; dp.f_kpar = dk; dp.f_spar = ds; dp.f_dtpar = ddt;
     dp.knots = dkn; dp.spl = dspl; dp.priors = dpri;
+    if ((st = e->sync_dp()) != LCF_OK) return bail(st);
     *out = e;
     return LCF_OK;
 }
@@ -2136,7 +2485,9 @@ lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant) {
     e->dp.variant = variant == 0 ? 0 : 1;
     e->dp.use_ctab = variant >= 2 ? 1 : 0;
     e->dp.use_itab = variant == 3 ? 1 : 0;
-    return LCF_OK;
+    LCF_HIP(hipSetDevice(e->device));
+    LCF_HIP(hipStreamSynchronize(e->stream));   // (launches in flight read the old copy)
+    return e->sync_dp();
 }
 
 lcf_status lcf_log_likelihood(lcf_engine* e, int64_t n, const double* P, double* out) {
@@ -2260,7 +2611,6 @@ struct lcf_sampler {
     DevSampler ds{};
     std::vector<void*> owned;
     double *coef = nullptr, *lprior = nullptr;
-    double2* therm = nullptr;
     // The state-independent draws of a run are produced in BLOCKS of steps, two buffers (block b lives in buffer b & 1):
     // device memory does not grow with the run, the first half-step starts after a short first block, and nothing on
     // the host waits for the generation.  The generation kernels go on the SAME stream as the half-steps, between two
@@ -2448,9 +2798,9 @@ lcf_status dalloc(T** p, size_t n, std::vector<void*>& owned) {
     return LCF_OK;
 }
 
-// Commit half-step g_next - 1 (if pending) and draw half-step g_next (if have_next).  `fuse_thermal`: also evaluate
-// the thermal states of slots [lo, hi) in the same launch.
-lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo, int hi, hipStream_t st) {
+// Commit half-step g_next - 1 (if pending) and draw half-step g_next (if have_next); coefficients and log-priors of the
+// slots [lo, hi) for the likelihood launch behind it.
+lcf_status launch_next(lcf_sampler* s, bool have_next, int lo, int hi, hipStream_t st) {
     lcf_engine* e = s->e;
     const DevSampler& ds = s->ds;
     const long long g = s->g_next;
@@ -2463,25 +2813,20 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
         if (lcf_status r = enter_half_step(s, rel, st)) return r;
     const DrawRec* draws = have_next ? s->rows(rel) : nullptr;
     const DrawRec* prev_draws = have_prev ? s->rows(rel - 1) : nullptr;
-    const bool thermal = have_next && fuse_thermal && e->dp.use_therm && hi > lo;
-    const int nec = thermal ? (e->dp.n_epochs + kBlock - 1) / kBlock : 1;
-    // without the thermal part only wave 0 of each workgroup has work: launch 64-thread workgroups then; with it,
-    // foreign slots take one wave each of the workgroups behind the shard's (see step_body)
-    const int bdim = thermal && e->dp.n_epochs > kFewEpochs ? kBlock : 64;
-    const int foreign = ds.n_half - (hi - lo), wpg = bdim / 64;
-    const unsigned groups = thermal ? (unsigned)((hi - lo) * nec + (foreign + wpg - 1) / wpg) : (unsigned)ds.n_half;
-#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3(groups), dim3(bdim), 0, st, \
+#define LCF_STEP(ND) hipLaunchKernelGGL(k_step<ND>, dim3((unsigned)ds.n_half), dim3(64), 0, st, \
                                         e->dp, ds, have_prev, prev_row, have_next ? 1 : 0, draws, prev_draws, g, lo, hi, \
-                                        nec, thermal ? 1 : 0, s->coef, s->lprior, s->therm)
+                                        s->coef, s->lprior)
     switch (ds.n_dim) {  // the fit dimensions of the supported models (+ sigma) get dedicated instantiations
+#ifndef LCF_DEV_BUILD
         case 2: LCF_STEP(2); break;
         case 3: LCF_STEP(3); break;
         case 4: LCF_STEP(4); break;
-        case 5: LCF_STEP(5); break;
         case 6: LCF_STEP(6); break;
         case 7: LCF_STEP(7); break;
-        case 8: LCF_STEP(8); break;
         case 9: LCF_STEP(9); break;
+#endif
+        case 5: LCF_STEP(5); break;
+        case 8: LCF_STEP(8); break;
         default: LCF_STEP(0); break;
     }
 #undef LCF_STEP
@@ -2494,12 +2839,11 @@ lcf_status launch_next(lcf_sampler* s, bool have_next, bool fuse_thermal, int lo
 }
 
 // Likelihood of the proposals [lo, hi) of the half-step drawn last.
-lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool finalize, hipStream_t st) {
+lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool finalize, hipStream_t st) {
     lcf_engine* e = s->e;
     if (hi <= lo) return LCF_OK;
     double* part = s->ds.part2[(s->g_next - 1) & 1];
-    launch_points<0>(e, lo, hi - lo, s->ds.Q[(s->g_next - 1) & 1], s->coef, s->lprior, s->therm, part, nullptr, st,
-                     !thermal_done);
+    launch_points<0>(e, lo, hi - lo, s->ds.Q[(s->g_next - 1) & 1], s->coef, s->lprior, nullptr, part, nullptr, st);
     if (finalize) {
         const int bs = 128;
         hipLaunchKernelGGL(k_finalize, dim3((hi - lo + bs - 1) / bs), dim3(bs), 0, st, e->dp, hi - lo,
@@ -2512,8 +2856,7 @@ lcf_status launch_eval(lcf_sampler* s, int lo, int hi, bool thermal_done, bool f
 constexpr size_t kLdsPerCU = 160 * 1024;
 
 size_t fused_lds_bytes(const lcf_engine* e) {
-    return e->lds_bytes + kFusedScratch * sizeof(double) +
-           (e->dp.use_therm ? (size_t)e->max_part_epochs * sizeof(double2) : 0);
+    return e->lds_bytes + kFusedScratch * sizeof(double);
 }
 
 bool fused_eligible(const lcf_sampler* s) {
@@ -2549,12 +2892,14 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
         else { if (e->dp.use_therm) LCF_FUSED3(ND, 1, true); else LCF_FUSED3(ND, 1, false); }      \
     } while (0)
     switch (ds.n_dim) {
+#ifndef LCF_DEV_BUILD
         case 4: LCF_FUSED(4); break;
-        case 5: LCF_FUSED(5); break;
         case 6: LCF_FUSED(6); break;
         case 7: LCF_FUSED(7); break;
-        case 8: LCF_FUSED(8); break;
         case 9: LCF_FUSED(9); break;
+#endif
+        case 5: LCF_FUSED(5); break;
+        case 8: LCF_FUSED(8); break;
         default: LCF_FUSED(0); break;
     }
 #undef LCF_FUSED
@@ -2569,8 +2914,7 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
 // ---- one workgroup per proposal (k_solo): single-GPU runs whose parts fit one workgroup -----------------------------
 size_t solo_lds_bytes(const lcf_engine* e) {
     return (kExpTabSize + 16) * sizeof(double) + (size_t)e->dp.stage_d2 * sizeof(double2) +
-           (kSoloScratch + 4) * sizeof(double) +
-           (e->dp.use_therm ? (size_t)e->dp.n_epochs * sizeof(double2) : 0);
+           (kSoloScratch + 4) * sizeof(double);
 }
 
 bool solo_eligible(const lcf_sampler* s) {
@@ -2581,6 +2925,18 @@ bool solo_eligible(const lcf_sampler* s) {
     // the serial head's registers on top of the point loop's do not fit 128 without spilling)
     return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.use_therm &&
            e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
+}
+
+// The model-specialised kernels (k_solo / k_pop <..., MODEL>) take engines of the shape the benchmarks have: a power-law
+// model (ShockCooling, ShockCooling2) without a fitted sigma, dense columns, interpolated band sums proved from their
+// first interval.  0: the generic kernel.
+int specialised_model(const DevProblem& dp) {
+    static const bool disabled = std::getenv("LCF_NO_SPECIALISED") != nullptr;
+    if (disabled || !dp.use_therm || !dp.use_itab || dp.variant == 0 || !dp.em_dense || !dp.itab_uniform || dp.use_sigma)
+        return 0;
+    if (dp.model == kShockCooling && dp.n_dim == 5) return kShockCooling;
+    if (dp.model == kShockCooling2 && dp.n_dim == 4) return kShockCooling2;
+    return 0;
 }
 
 // One half-step of a single-GPU run: ONE launch, one workgroup per proposal, accept test and commit included.
@@ -2596,18 +2952,20 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
     const long long row = rel / 2, G = s->g_run0 + rel, g_run0 = s->g_run0;
     const dim3 grid((unsigned)(board ? hi - lo : ds.n_half));
     if (board && hi <= lo) return leave_half_step(s, st);
+    const int spec = specialised_model(e->dp);
+#define LCF_SOLO6(ND, V, T, NP, B, M)                                                                                 \
+    do {                                                                                                              \
+        if (lds > 64 * 1024) /* allow more than the default 64 KiB of dynamic LDS (per function and device) */       \
+            LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP, B, M>,                                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));                 \
+        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, ds, row, draws,    \
+                           draws_next, G, g_run0, lo);                                                                \
+    } while (0)
 #define LCF_SOLO5(ND, V, T, NP, B)                                                                                    \
     do {                                                                                                              \
-        if (lds > 64 * 1024) {                                                                                        \
-            static bool raised = false; /* per instantiation: allow more than the default 64 KiB of dynamic LDS */   \
-            if (!raised) {                                                                                            \
-                LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP, B>,                                     \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));             \
-                raised = true;                                                                                        \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B>), grid, dim3(kBlock * 2), lds, st, e->dp, ds, row, draws,         \
-                           draws_next, G, g_run0, lo);                                                                \
+        if (ND == 5 && spec == kShockCooling) LCF_SOLO6(5, V, T, NP, B, kShockCooling);                               \
+        else if (ND == 4 && spec == kShockCooling2) LCF_SOLO6(4, V, T, NP, B, kShockCooling2);                        \
+        else LCF_SOLO6(ND, V, T, NP, B, 0);                                                                           \
     } while (0)
 #define LCF_SOLO4(ND, V, T, NP)                                                                                       \
     do {                                                                                                              \
@@ -2620,18 +2978,21 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
     } while (0)
 #define LCF_SOLO(ND) LCF_SOLO3(ND, 1, true)
     switch (ds.n_dim) {
+#ifndef LCF_DEV_BUILD
         case 4: LCF_SOLO(4); break;
-        case 5: LCF_SOLO(5); break;
         case 6: LCF_SOLO(6); break;
         case 7: LCF_SOLO(7); break;
-        case 8: LCF_SOLO(8); break;
         case 9: LCF_SOLO(9); break;
+#endif
+        case 5: LCF_SOLO(5); break;
+        case 8: LCF_SOLO(8); break;
         default: LCF_SOLO(0); break;
     }
 #undef LCF_SOLO
 #undef LCF_SOLO3
 #undef LCF_SOLO4
 #undef LCF_SOLO5
+#undef LCF_SOLO6
     LCF_HIP(hipGetLastError());
     return leave_half_step(s, st);
 }
@@ -2653,20 +3014,20 @@ lcf_status launch_half_step_sharded(lcf_sampler* s, int lo, int hi, hipStream_t 
         if (lcf_status r = launch_fused(s, lo, hi, st)) return r;
         return launch_finalize(s, lo, hi, st);
     }
-    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, true, st);  // launch_next computed the thermal states
+    if (lcf_status r = launch_next(s, true, lo, hi, st)) return r;
+    return launch_eval(s, lo, hi, true, st);
 }
 
 // The same without the finalize launch: the shard's rows (partial sums + log-prior) are the result.
 lcf_status launch_half_step_rows(lcf_sampler* s, int lo, int hi, hipStream_t st) {
     if (fused_eligible(s) && hi > lo) return launch_fused(s, lo, hi, st);
-    if (lcf_status r = launch_next(s, true, true, lo, hi, st)) return r;
-    return launch_eval(s, lo, hi, s->e->dp.use_therm != 0, false, st);
+    if (lcf_status r = launch_next(s, true, lo, hi, st)) return r;
+    return launch_eval(s, lo, hi, false, st);
 }
 
 lcf_status flush_pending(lcf_sampler* s, hipStream_t st) {
     if (!s->pending) return LCF_OK;
-    return launch_next(s, false, false, 0, 0, st);
+    return launch_next(s, false, 0, 0, st);
 }
 
 // Commit what is pending and copy the snapshot behind it, all on the engine's stream; enqueue only.
@@ -2842,7 +3203,6 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     }
     AL(s->coef, nh * kNCoef); AL(s->lprior, nh);
     for (int b = 0; b < 2; ++b) AL(ds.part2[b], nh * (e->dp.n_parts + 1));
-    if (e->dp.use_therm) AL(s->therm, nh * e->dp.n_epochs);
 #undef AL
     LCF_HIP(hipMemset(ds.nacc, 0, nw * sizeof(long long)));
     LCF_HIP(hipMemset(ds.err, 0, sizeof(int)));
@@ -2900,7 +3260,7 @@ lcf_status lcf_sampler_propose(lcf_sampler* s, int64_t step, int32_t half, void*
     if (g != s->g_next) return fail(LCF_ERR_STATE, "half-steps must be proposed in order, each exactly once");
     s->ds.inline_finalize = 0;  // accept tests read the gathered newlp
     // the shard is not known yet: every slot gets its coefficients (lcf_sampler_half_step knows it and is cheaper)
-    return launch_next(s, true, false, 0, s->ds.n_half, stream ? (hipStream_t)stream : s->e->stream);
+    return launch_next(s, true, 0, s->ds.n_half, stream ? (hipStream_t)stream : s->e->stream);
 }
 // propose + evaluate in one call: the shard is known, so the thermal states of [lo, hi) are computed by the same
 // launch that draws the proposals (3 launches per half-step and rank: k_step, k_points, k_finalize).
@@ -2918,7 +3278,7 @@ lcf_status lcf_sampler_half_step(lcf_sampler* s, int64_t step, int32_t half, int
 lcf_status lcf_sampler_evaluate(lcf_sampler* s, int32_t lo, int32_t hi, void* stream) {
     if (!s || lo < 0 || hi < lo || hi > s->ds.n_half) return fail(LCF_ERR_INVALID_ARGUMENT, "bad shard range");
     if (!s->pending) return fail(LCF_ERR_STATE, "lcf_sampler_propose must precede lcf_sampler_evaluate");
-    return launch_eval(s, lo, hi, false, true, stream ? (hipStream_t)stream : s->e->stream);
+    return launch_eval(s, lo, hi, true, stream ? (hipStream_t)stream : s->e->stream);
 }
 lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* stream) {
     if (!s || half < 0 || half > 1 || step < s->run_first || step >= s->run_first + s->run_steps)
@@ -3353,8 +3713,8 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
             if (lcf_status r = launch_fused(s, 0, s->ds.n_half, st)) return r;
             continue;
         }
-        if (lcf_status r = launch_next(s, true, true, 0, s->ds.n_half, st)) return r;
-        if (lcf_status r = launch_eval(s, 0, s->ds.n_half, s->e->dp.use_therm != 0, false, st)) return r;
+        if (lcf_status r = launch_next(s, true, 0, s->ds.n_half, st)) return r;
+        if (lcf_status r = launch_eval(s, 0, s->ds.n_half, false, st)) return r;
     }
     if (lcf_status r = flush_pending(s, st)) return r;
     LCF_HIP(hipEventRecord(s->ev1, st));
@@ -3401,7 +3761,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     }
     std::vector<MultiItem> items(n);
     size_t lds = 0;
-    int max_nec = 1, max_parts = 1, max_epochs = 0;
+    int max_parts = 1;
     const bool thermal = s0->e->dp.use_therm != 0;
     int same_dim = s0->ds.n_dim;  // compile-time walker dimension when every transient has the same
     for (int t = 0; t < n; ++t)
@@ -3411,7 +3771,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         s->g_next = s->g_run0 = g;  // lock-step half-step numbering across the population
         s->ds.inline_finalize = 1;
         items[t] = MultiItem{s->e->dp, s->ds, {s->d_draws[0], s->d_draws[1]}, (long long)s->blk_first,
-                             (long long)s->blk_steps, s->coef, s->lprior, s->therm};
+                             (long long)s->blk_steps, s->coef, s->lprior};
         // With many transients in one launch a single workgroup per proposal already fills the chip, and it stages
         // the tables and reduces once for all of the proposal's chunks: fewer parts than the engine's default.
         DevProblem& ip = items[t].pb;
@@ -3421,12 +3781,12 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         const int mg = (ip.n_parts + parts - 1) / parts;  // engine parts merged into one workgroup's share
         const int np = (ip.n_parts + mg - 1) / mg;
         const DevProblem& ep = s->e->dp;
-        for (int J = 0; J <= kMaxParts; ++J)
+        for (int J = 0; J <= kMaxParts; ++J) {
             ip.part_start[J] = J < np ? ep.part_start[J * mg] : ep.n_points;
+            ip.part_col0[J] = J < np ? ep.part_col0[J * mg] : ep.em_cols;
+        }
         ip.n_parts = np;
         lds = std::max(lds, s->e->lds_bytes);
-        max_epochs = std::max(max_epochs, s->e->dp.n_epochs);
-        max_nec = std::max(max_nec, thermal ? (s->e->dp.n_epochs + kBlock - 1) / kBlock : 1);
         max_parts = std::max(max_parts, items[t].pb.n_parts);
     }
     // One launch per half-step (k_pop: a workgroup per four proposals, accept test included) where every transient has
@@ -3444,10 +3804,12 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int t = 0; t < n && one_launch; ++t) {
         const DevProblem& ip = items[t].pb;
         pop_lds = std::max(pop_lds, (kExpTabSize + 16) * sizeof(double) + (size_t)ip.stage_d2 * sizeof(double2) +
-                                        (size_t)pop_group * (kPopScratch + 4 * kPopMaxParts) * sizeof(double) +
-                                        (size_t)pop_group * ip.n_epochs * sizeof(double2));
+                                        (size_t)pop_group * (kPopScratch + 4 * kPopMaxParts) * sizeof(double));
     }
     one_launch = one_launch && pop_lds <= kLdsPerCU;
+    int pop_spec = specialised_model(items[0].pb);   // every transient of the population of that shape, or the generic kernel
+    for (int t = 1; t < n; ++t)
+        if (specialised_model(items[t].pb) != pop_spec) pop_spec = 0;
     LCF_HIP(hipSetDevice(s0->e->device));
     MultiItem* ditems = nullptr;
     LCF_HIP(hipMalloc((void**)&ditems, (size_t)n * sizeof(MultiItem)));
@@ -3456,25 +3818,31 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     const int nh = s0->ds.n_half;
     hipEvent_t ev0 = s0->ev0, ev1 = s0->ev1;
     if (err == hipSuccess) err = hipEventRecord(ev0, st);
-    const dim3 gs((unsigned)(nh * max_nec), (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
-    const dim3 bs(thermal && max_epochs > kFewEpochs ? kBlock : 64), bp(kBlock);
+    const dim3 gs((unsigned)nh, (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
+    const dim3 bs(64), bp(kBlock);
     if (one_launch) {
         const dim3 gq((unsigned)((nh + pop_group - 1) / pop_group), (unsigned)n), bq(64 * pop_group);
         for (int64_t k = 0; k < 2 * n_steps && err == hipSuccess; ++k) {
             for (int t = 0; t < n && err == hipSuccess; ++t)
                 if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
             if (err != hipSuccess) break;
-#define LCF_POP2(ND, G) do { allow_lds(k_pop<ND, 1, G>, pop_lds);                                                   \
-                             hipLaunchKernelGGL((k_pop<ND, 1, G>), gq, bq, pop_lds, st, ditems, (long long)k); } while (0)
+#define LCF_POP3(ND, G, M) do { allow_lds(k_pop<ND, 1, G, M>, pop_lds);                                             \
+                                hipLaunchKernelGGL((k_pop<ND, 1, G, M>), gq, bq, pop_lds, st, ditems, (long long)k); } while (0)
+#define LCF_POP2(ND, G) do { if (ND == 5 && pop_spec == kShockCooling) LCF_POP3(5, G, kShockCooling);               \
+                             else if (ND == 4 && pop_spec == kShockCooling2) LCF_POP3(4, G, kShockCooling2);        \
+                             else LCF_POP3(ND, G, 0); } while (0)
 #define LCF_POP(ND) LCF_POP2(ND, pop_group)
             switch (same_dim) {
+#ifndef LCF_DEV_BUILD
                 case 4: LCF_POP(4); break;
-                case 5: LCF_POP(5); break;
                 case 6: LCF_POP(6); break;
+#endif
+                case 5: LCF_POP(5); break;
                 case 8: LCF_POP(8); break;
                 default: LCF_POP(0); break;
             }
 #undef LCF_POP2
+#undef LCF_POP3
 #undef LCF_POP
             for (int t = 0; t < n && err == hipSuccess; ++t) {
                 if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
@@ -3490,14 +3858,14 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             for (int t = 0; t < n && err == hipSuccess; ++t)
                 if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
         if (err != hipSuccess) break;
-#define LCF_STEPM(ND) hipLaunchKernelGGL(k_step_multi<ND>, have_next ? gs : dim3((unsigned)nh, (unsigned)n),              \
-                                         have_next ? bs : dim3(64), 0, st, ditems, have_prev ? 1 : 0,                  \
-                                         (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k, (long long)(g + k), \
-                                         (have_next && thermal) ? 1 : 0)
+#define LCF_STEPM(ND) hipLaunchKernelGGL(k_step_multi<ND>, gs, bs, 0, st, ditems, have_prev ? 1 : 0,                      \
+                                         (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k, (long long)(g + k))
         switch (same_dim) {
+#ifndef LCF_DEV_BUILD
             case 4: LCF_STEPM(4); break;
-            case 5: LCF_STEPM(5); break;
             case 6: LCF_STEPM(6); break;
+#endif
+            case 5: LCF_STEPM(5); break;
             case 8: LCF_STEPM(8); break;
             default: LCF_STEPM(0); break;
         }
@@ -3564,5 +3932,8 @@ double lcf_sampler_last_run_ms(const lcf_sampler* s) { return s ? s->last_ms : 0
 #ifdef LCF_STAMPS
 extern "C" int lcf_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+extern "C" int lcf_debug_read_wall(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wall), sizeof(unsigned long long) * 2 * 1024 * 2);
 }
 #endif

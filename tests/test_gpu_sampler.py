@@ -319,10 +319,10 @@ def test_chain_matches_oracle_on_a_multiband_grid(model_name):
     assert np.array_equal(chain, s.get_chain()) and np.array_equal(lp, s.get_log_prob())
 
 
-def test_long_light_curve_takes_the_two_kernel_path():
-    """186 000 points in 31 000 epochs: 8 parts of ~3900 epochs each do not fit the LDS budget of the one-launch
-    half-step, so the run falls back to k_step + k_points (same chain as the separate phases, bit for bit); the
-    likelihoods of the final ensemble against the oracle."""
+def test_long_light_curve_one_launch_and_phases():
+    """186 000 points in 31 000 epochs, 8 parts of ~3900 columns each: the thermal states are the lanes' own (no LDS
+    budget per epoch any more), so the run is one launch per half-step (k_fused: 8 parts) -- and the same chain as the
+    separate phases (k_step + k_points), bit for bit; the likelihoods of the final ensemble against the oracle."""
     from lightcurve_fitting_amd.engine import NativeSampler
     rng = np.random.default_rng(99)
     epochs = np.sort(rng.uniform(0.4, 30., 31000))
@@ -338,9 +338,10 @@ def test_long_light_curve_takes_the_two_kernel_path():
     eng = m.engine_for(lc_dict(t, names, y, dy), priors=priors)
     x0 = truth * (1 + 0.002 * rng.standard_normal((16, 5)))
     a = NativeSampler(eng, 16, 5)
-    assert not a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
+    assert a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
     a.set_state(x0)
     a.run(0, 3, 'random', True)
+    assert a.last_run_kernel() == 'fused'
     b = NativeSampler(eng, 16, 5)
     b.set_state(x0)
     b.begin(0, 3, 'random', True)

@@ -293,23 +293,25 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
     for m in re.finditer(r'Function Name: (\S+)(.*?)(?=Function Name:|\Z)', text, re.S):
         fields = dict(re.findall(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)', m.group(2)))
         blocks[m.group(1)] = fields
-    # k_solo<ND = 4..9, fast band sum, shared epochs, 512- and 1024-thread workgroups>, k_fused<ND = 4..9, both thermal
-    # modes>, k_points<fast band sum, likelihood mode, tables staged, both thermal modes>
-    # (k_solo also in its row-board form, the multi-GPU run in which every rank moves its own share of the walkers)
-    hot = [k for k in blocks if re.search(r'k_soloILi[4-9]ELi1ELb1ELi[24]ELb[01]E', k) or
-           re.search(r'k_fusedILi[4-9]ELi1ELb[01]E', k) or re.search(r'k_pointsILi1ELi0ELb1ELb[01]E', k)]
-    assert len(hot) == 24 + 14, sorted(blocks)[:5]
+    # k_solo<ND = 4..9, fast band sum, epoch-major likelihood, two / four parts, single-GPU and row-board form, generic
+    # model> + its model-specialised instantiations (ShockCooling: ND 5, ShockCooling2: ND 4 -- the benchmark kernels),
+    # k_fused<ND = 4..9, both thermal modes>, k_points<fast band sum, likelihood mode, tables staged, both thermal modes>
+    solo = [k for k in blocks if re.search(r'k_soloILi[4-9]ELi1ELb1ELi[24]ELb[01]ELi[012]E', k)]
+    special = [k for k in solo if re.search(r'ELi[12]EEEv', k)]
+    hot = solo + [k for k in blocks if re.search(r'k_fusedILi[4-9]ELi1ELb[01]E', k) or
+                  re.search(r'k_pointsILi1ELi0ELb1ELb[01]E', k)]
+    assert len(solo) == 24 + 8 and len(special) == 8 and len(hot) == 32 + 14, sorted(blocks)[:5]
     for k in hot:
         f = blocks[k]
         assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0, (k, f)
-        # scalar registers spill into lanes of a vector register: at most two registers' worth with shared epochs (the
-        # paths fits run on), three with the thermal state inside the point loop
-        shared_epochs = re.search(r'k_(solo|fused)ILi\dELi1ELb1E', k) or re.search(r'k_pointsILi1ELi0ELb1ELb1E', k)
-        assert int(f['SGPRs Spill']) <= (128 if shared_epochs else 192), (k, f)
+        # scalar registers spill into lanes of a vector register (cheap, but every spill is an instruction in a kernel
+        # that is bound by instruction issue): the benchmark kernels stay under one register's worth, the generic ones
+        # -- every model's arithmetic behind run-time switches -- under four
+        assert int(f['SGPRs Spill']) <= (64 if k in special else 224), (k, f)
         assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
     # population mode's one launch per half-step, in the dimensions with their own instantiation
-    pops = [k for k in blocks if re.search(r'k_popILi[4568]ELi1ELi4E', k)]
-    assert len(pops) == 4, sorted(blocks)[:5]
+    pops = [k for k in blocks if re.search(r'k_popILi[4568]ELi1ELi4ELi[012]E', k)]
+    assert len(pops) == 4 + 2, sorted(blocks)[:5]
     for k in pops:
         f = blocks[k]
         assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0 and int(f['Occupancy']) >= 4, (k, f)

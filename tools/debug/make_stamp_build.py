@@ -12,7 +12,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.makedirs(os.path.join(ROOT, 'build_variants'), exist_ok=True)
 csrc = os.path.join(ROOT, 'lightcurve_fitting_amd', 'csrc')
-subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-DLCF_STAMPS',
+subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-DLCF_STAMPS', '-DLCF_DEV_BUILD',
                 '-I' + os.path.join(ROOT, 'include'), '-Wno-unused-value', '-ffp-contract=on', '-mllvm', '-disable-machine-licm', '-shared', '-o',
                 os.path.join(ROOT, 'build_variants/liblcf_stamps.so'), os.path.join(csrc, 'lcf_hip.hip'),
                 os.path.join(csrc, 'lcf_sed.hip')], check=True)

@@ -23,13 +23,30 @@ lib.lcf_debug_read_stamps.argtypes = [C.c_void_p]
 lib.lcf_debug_read_stamps(buf)
 a = np.array(buf[:], dtype=np.int64).reshape(64, 16)
 names = ['entry->draw record', 'walker rows + proposal', 'logarithms', 'coefficients', 'priors + LDS publish',
-         'barrier', 'coefficients to SGPRs + thermal states', 'points', 'wave sums + barrier', 'accept + commit']
+         'barrier', 'coefficients to SGPRs', 'columns (states + points)', 'wave sums + barrier', 'accept + commit']
 d = np.diff(a[:, :11], axis=1)
 for n, v in zip(names, np.median(d, axis=0)):
     print(f'{n:45s} {v:9.0f}')
-print('total', np.median(a[:, 10] - a[:, 0]), ' spread of entry stamps over the 64 workgroups', np.ptp(a[:, 0]))
-print('wave 1: staging done at', np.median(a[:, 11] - a[:, 0]), ' points done at', np.median(a[:, 12] - a[:, 0]),
+tot = a[:, 10] - a[:, 0]
+print('total: median', np.median(tot), ' min', tot.min(), ' p90', np.percentile(tot, 90), ' max', tot.max())
+print('per phase p90:', ' '.join(f'{v:.0f}' for v in np.percentile(d, 90, axis=0)))
+print('per phase max:', ' '.join(f'{v:.0f}' for v in d.max(axis=0)))
+print('wave 1: staging done at', np.median(a[:, 11] - a[:, 0]), ' columns done at', np.median(a[:, 12] - a[:, 0]),
       '(wave 0:', np.median(a[:, 8] - a[:, 0]), ')')
-print('points loop, wave 0: operands of the first iteration after', np.median(a[:, 13] - a[:, 7]), ' first iteration done after',
-      np.median(a[:, 14] - a[:, 7]), ' all iterations', np.median(a[:, 8] - a[:, 7]))
+print('columns, wave 0: thermal state after', np.median(a[:, 13] - a[:, 7]), ' first three filters after',
+      np.median(a[:, 14] - a[:, 7]), ' next three after', np.median(a[:, 15] - a[:, 7]), ' all', np.median(a[:, 8] - a[:, 7]))
 print('device ms per step', s.last_run_ms / nst)
+
+# chip-wide timeline of the last two launches (100 MHz wall clock, the same on every XCD)
+wb = (C.c_ulonglong * (2 * 1024 * 2))()
+lib.lcf_debug_read_wall.argtypes = [C.c_void_p]
+lib.lcf_debug_read_wall(wb)
+w = np.array(wb[:], dtype=np.int64).reshape(2, 1024, 2)[:, :nw // 2, :]
+order = np.argsort([w[0, :, 0].min(), w[1, :, 0].min()])
+first, second = w[order[0]], w[order[1]]
+for name, x in (('earlier launch', first), ('later launch', second)):
+    e, q = x[:, 0], x[:, 1]
+    print(f'{name}: entries spread over {(e.max() - e.min()) / 100:.2f} us, exits over {(q.max() - q.min()) / 100:.2f} us, '
+          f'first entry -> last exit {(q.max() - e.min()) / 100:.2f} us, median lifetime {np.median(q - e) / 100:.2f} us')
+print(f'last exit of the earlier launch -> first entry of the later one: {(second[:, 0].min() - first[:, 1].max()) / 100:.2f} us; '
+      f'first entry -> first entry: {(second[:, 0].min() - first[:, 0].min()) / 100:.2f} us')
