@@ -560,31 +560,43 @@ __global__ __launch_bounds__(kBlock) void k_thermal(const DevProblem pb, int w_l
     therm[(size_t)w * pb.n_epochs + ep] = make_double2(invT, pref);
 }
 
-// Stage the exp table and ALL band tables in LDS; thread t of nt.  ShockCooling3: the walker's reddening goes into
-// the staged weights.
+// Stage the exp table and the staged region (band tables, descriptors, interpolants) in LDS; thread t of nt.  One flat
+// copy of the engine's image of that layout, eight 16-byte loads per thread in flight before the first LDS store: a
+// loop of load -> store pairs is one memory round trip per iteration, and six of them in a row made staging as long
+// as the whole serial head (configs[1]: staged at 5.4 k cycles after kernel entry, now at 4.4 k; half-step 7.82 ->
+// 7.51 us).  ShockCooling3: the walker's reddening goes into the staged weights (table by table).
 template <int VARIANT, bool LDS_TAB>
 __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ exptab, double2* __restrict__ ltab,
                                     double ebv, int t, int nt) {
-    if (VARIANT == 1)
+    if (LDS_TAB && pb.model == kShockCooling3 && !pb.redden_slow) {
         for (int k = t; k < kExpTabSize; k += nt) exptab[k] = pb.exp2tab[k];
-    if (LDS_TAB) {
-        // filter descriptors (48 B = 3 double2 each) behind the tables
-        double2* lfd = ltab + pb.n_lds_tab;
+        double2* lfd = ltab + pb.n_lds_tab;   // filter descriptors (48 B = 3 double2 each) behind the tables
         const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
         for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
-        // ... and the filters' interpolants behind those
-        double2* lit = lfd + 3 * pb.n_filters;
-        const double2* git = reinterpret_cast<const double2*>(pb.itab);
-        for (int k = t; k < pb.n_itab_lds / 2; k += nt) lit[k] = git[k];
-        if (pb.model == kShockCooling3 && !pb.redden_slow) {
-            for (int k = t; k < pb.n_lds_tab; k += nt) {
-                double2 aw = pb.tab[k];
-                aw.y *= exp2(-ebv * pb.tab_ext[k]);
-                ltab[k] = aw;
-            }
-        } else {
-            for (int k = t; k < pb.n_lds_tab; k += nt) ltab[k] = pb.tab[k];
+        for (int k = t; k < pb.n_lds_tab; k += nt) {
+            double2 aw = pb.tab[k];
+            aw.y *= exp2(-ebv * pb.tab_ext[k]);
+            ltab[k] = aw;
         }
+        return;
+    }
+    const int n16 = LDS_TAB ? pb.stage_n16 : kLdsHead / 2;
+    const double2* __restrict__ g = pb.stage_image;
+    double2* __restrict__ l = reinterpret_cast<double2*>(exptab);
+    const int last = n16 - 1;
+#pragma unroll 1
+    for (int k0 = t; k0 < n16; k0 += 8 * nt) {   // (named values, not an array: that the compiler kept in scratch memory)
+        const int k1 = k0 + nt, k2 = k1 + nt, k3 = k2 + nt, k4 = k3 + nt, k5 = k4 + nt, k6 = k5 + nt, k7 = k6 + nt;
+        const double2 v0 = g[min(k0, last)], v1 = g[min(k1, last)], v2 = g[min(k2, last)], v3 = g[min(k3, last)];
+        const double2 v4 = g[min(k4, last)], v5 = g[min(k5, last)], v6 = g[min(k6, last)], v7 = g[min(k7, last)];
+        l[k0] = v0;
+        if (k1 < n16) l[k1] = v1;
+        if (k2 < n16) l[k2] = v2;
+        if (k3 < n16) l[k3] = v3;
+        if (k4 < n16) l[k4] = v4;
+        if (k5 < n16) l[k5] = v5;
+        if (k6 < n16) l[k6] = v6;
+        if (k7 < n16) l[k7] = v7;
     }
 }
 
@@ -699,7 +711,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);                     // kExpTabSize doubles
     double* red = exptab + kExpTabSize;                                   // 4 doubles
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
+    double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
 
     const int part = bid / n_w;
     const int w = w_lo + bid % n_w;
@@ -714,7 +726,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab) : pb.f_desc;
     // byte offset of the staged interpolants in the dynamic LDS (behind the tables and descriptors), or -1
     const int itab_at = (LDS_TAB && pb.n_itab_lds > 0)
-                            ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     if constexpr (MODE == 0 && THERM) {
         // (the thermal states are the lanes' own: k_thermal is not launched for the likelihood)
         const double term = epochs_loop<VARIANT, LDS_TAB>(pb, part, P + (size_t)w * pb.n_dim, c, tbase, fdesc, ExpTab{exptab},
@@ -1196,10 +1208,10 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     extern __shared__ __align__(16) unsigned char smem[];
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 8) * sizeof(double));
+    double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)((kExpTabSize + 8) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);
     double* sq = sc + kNCoef + 2;
     const int tid = threadIdx.x;
@@ -1476,10 +1488,10 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
+    double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);  // coefficients, then log-prior
     double* sq = sc + kNCoef + 2;                                           // the proposal
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
@@ -1762,10 +1774,10 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
     const int nh = sm.n_half, slot0 = blockIdx.x * GROUP;
     if (slot0 >= nh) return;
     double* exptab = reinterpret_cast<double*>(smem);
-    double2* ltab = reinterpret_cast<double2*>(smem + (kExpTabSize + 16) * sizeof(double));
+    double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)((kExpTabSize + 16) * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
     double* scratch = reinterpret_cast<double*>(ltab + pb.stage_d2);       // [GROUP][kPopScratch]
     double* red = scratch + GROUP * kPopScratch;                             // [GROUP][4 * kPopMaxParts] wave sums
     constexpr int kD = ND > 0 ? ND : kMaxDim;
@@ -2372,7 +2384,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.log_norm_const = lognorm;
     dp.sigma_unit_abs = med;
     e->samples_per_eval = samples * (pr->model == LCF_MODEL_SHOCK_COOLING4 ? 2 : 1);
-    e->lds_bytes = (kExpTabSize + 8) * sizeof(double) + (dp.tab_in_lds ? (size_t)dp.stage_d2 * sizeof(double2) : 0);
+    e->lds_bytes = kLdsHead * sizeof(double) + (dp.tab_in_lds ? (size_t)dp.stage_d2 * sizeof(double2) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
     int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
@@ -2398,6 +2410,23 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     FiltDesc* dfd;
     double *dexp, *depocht, *dinvdy;
     UP(hexp, dexp); UP(hepoch, depoch); UP(epochs, depocht);
+    {   // the image of the kernels' staged LDS (see kLdsHead / stage_tables)
+        std::vector<double2> himg(kLdsHead / 2, make_double2(0., 0.));
+        std::memcpy(himg.data(), hexp.data(), kExpTabSize * sizeof(double));
+        if (dp.tab_in_lds) {
+            himg.insert(himg.end(), htab.begin(), htab.begin() + dp.n_lds_tab);
+            const double2* fd2 = reinterpret_cast<const double2*>(hfd.data());
+            himg.insert(himg.end(), fd2, fd2 + 3 * NF);
+            for (int k = 0; k < dp.n_itab_lds; k += 2) {
+                const double a = pr->itab_coef[k], b = pr->itab_coef[k + 1];
+                himg.push_back(make_double2(std::isfinite(a) ? a : 0., std::isfinite(b) ? b : 0.));
+            }
+        }
+        double2* dimg;
+        UP(himg, dimg);
+        dp.stage_image = dimg;
+        dp.stage_n16 = (int)himg.size();
+    }
     {   // observation and the factor its residual is scaled with, side by side
         std::vector<double2> hyd(N);
         for (int i = 0; i < N; ++i) hyd[i] = make_double2(hy[i], pr->use_sigma ? hdy[i] : hinvdy[i]);
@@ -2913,7 +2942,7 @@ lcf_status launch_fused(lcf_sampler* s, int lo, int hi, hipStream_t st) {
 
 // ---- one workgroup per proposal (k_solo): single-GPU runs whose parts fit one workgroup -----------------------------
 size_t solo_lds_bytes(const lcf_engine* e) {
-    return (kExpTabSize + 16) * sizeof(double) + (size_t)e->dp.stage_d2 * sizeof(double2) +
+    return kLdsHead * sizeof(double) + (size_t)e->dp.stage_d2 * sizeof(double2) +
            (kSoloScratch + 4) * sizeof(double);
 }
 
@@ -3803,7 +3832,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int t = 0; t < n; ++t) one_launch = one_launch && ss[t]->e->dp.model != kShockCooling3;
     for (int t = 0; t < n && one_launch; ++t) {
         const DevProblem& ip = items[t].pb;
-        pop_lds = std::max(pop_lds, (kExpTabSize + 16) * sizeof(double) + (size_t)ip.stage_d2 * sizeof(double2) +
+        pop_lds = std::max(pop_lds, kLdsHead * sizeof(double) + (size_t)ip.stage_d2 * sizeof(double2) +
                                         (size_t)pop_group * (kPopScratch + 4 * kPopMaxParts) * sizeof(double));
     }
     one_launch = one_launch && pop_lds <= kLdsPerCU;
