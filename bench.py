@@ -60,20 +60,27 @@ ALG_BYTES = 8 * (5 + 1)                                        # HBM bytes per w
 PEAK_FP64_TINSTR = 256 * 64 * 2.4e9 / 1e12                     # 39.3 T FP64 lane-instructions/s (= 78.6 TFLOP/s FMA)
 PEAK_FP32_TINSTR = 2 * PEAK_FP64_TINSTR                        # 157.3 TFLOP/s FMA
 PEAK_HBM_GBS = 8000.
-# Vector-ALU instructions per quad of samples in the shipped band-sum loop (58 FP64 + 23 other: exp via table and
-# degree-4 polynomial, four samples sharing one division), counted in the ISA of k_solo<5,1,true,2> by
-# tools/isa_count.py; the float32 SED loop (k_sed<1>, hardware exponential and reciprocal): 21 per quad
-VALU_PER_QUAD_F64 = 81
+# The float32 SED loop (k_sed<1>, hardware exponential and reciprocal): vector-ALU instructions per quad of samples
 VALU_PER_QUAD_F32 = 21
-# ... per data point on the interpolated path (variant 3: interval + Horner on 8 coefficients + one exponential +
-# residual: 25 FP64 + 30 other, from the same listing) and per epoch of the log-space thermal state (short logarithm +
-# table exponential: 140 with libm's, and SQ_INSTS_VALU per wave -- one epoch per lane -- fell by 55 with the switch)
-# (two points of a lane are interpolated side by side since the end of round 2: interval, eight coefficients, Horner,
-# exponent, table exponential and residual take 72 vector-ALU instructions per pair; SQ_INSTS_VALU per wave fell from 795
-# to 650 with that path -- six points per lane -- because the per-point bookkeeping of the general code went with it)
-VALU_PER_POINT_INTERP = 36        # power-law models (ShockCooling, ShockCooling2): the two-point path
-VALU_PER_POINT_INTERP_GENERAL = 55  # every other model: point by point, per-wave choice of the path included
-VALU_PER_EPOCH_LOG = 85
+
+
+def isa_counts():
+    """Vector-ALU instructions per unit of work of the shipped loops, counted by the BUILD in the ISA of the library that
+    runs (csrc/liblcf_hip.isa.json, written by the Makefile through tools/isa_count.py):
+      quad_main   one trip of the band-sum loop over four Planck samples (exp via table + degree-4 polynomial, four
+                  samples sharing one division)
+      point_lean  one interpolated data point (interval, Horner on 8 coefficients, one table exponential, residual) of
+                  the model-specialised half-step kernel; every other model's points are priced with the same number (what
+                  they execute at least)
+      state_lean  one log-space thermal state of a power-law model (short logarithm + table exponential)
+      log_lean    its logarithm alone: the price of the state of a model that needs nothing else (companion shocking)
+    Nothing here is typed in: without the report there is no roofline basis, and the line says so."""
+    path = os.path.join(ROOT, 'lightcurve_fitting_amd', 'csrc', 'liblcf_hip.isa.json')
+    try:
+        doc = json.load(open(path))
+        return {k: float(doc[k]) for k in ('quad_main', 'quad_safe', 'point_lean', 'state_lean', 'log_lean')}, None
+    except Exception as exc:  # noqa: BLE001
+        return None, f'no ISA report next to the library ({type(exc).__name__}): build with make -C lightcurve_fitting_amd/csrc'
 
 
 # =====================================================================================================================
@@ -180,9 +187,10 @@ def max_over_ranks(dist, elapsed):
     return float(tmax.item())
 
 
-def timed_run(sampler, dist, warmup, steps, x0):
+def timed_run(sampler, dist, warmup, steps, x0, store=True):
     """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the maximum
-    over the ranks."""
+    over the ranks.  `store`: the timed run keeps its chain (every walker's position and log-posterior after every step,
+    in HBM), as the reference's sampling run does (fitting.py:144-148: emcee's default)."""
     import torch
 
     def barrier():
@@ -197,10 +205,12 @@ def timed_run(sampler, dist, warmup, steps, x0):
         gc.collect()     # once in eight 0.6 ms runs, tools/debug/short_run_breakdown.py) is not the sampler's time.
         gc.disable()     # Collected BEFORE the warm-up (the caller may have done it even earlier, see quiet_interpreter):
     try:                 # the timed steps must follow busy work without a pause in which the device clocks down.
+        if store:
+            sampler.reserve_chain(steps)              # (the chain's device memory: allocated with everything else)
         sampler.run_mcmc(x0, warmup, store=False)     # untimed warm-up (also allocates everything)
         barrier()
         t0 = time.perf_counter()
-        sampler.run_mcmc(None, steps, store=False)    # returns after the device has finished
+        sampler.run_mcmc(None, steps, store=store)    # returns after the device has finished
         barrier()
         elapsed = time.perf_counter() - t0
     finally:
@@ -336,20 +346,25 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
     the interpolated path (variant 3), counted at their own instruction counts; `quads_per_eval` then covers only the
     points that walk sample tables."""
     sec = kern_ms * 1e-3
+    isa, isa_note = isa_counts()
+    if valu_per_quad is None:      # float64 band sums: from the build's report
+        valu_per_quad = isa['quad_main'] if isa else float('nan')
     per_eval = quads_per_eval * valu_per_quad
-    basis = (f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x {valu_per_quad} '
+    basis = (f'{quads_per_eval:.0f} quads of samples per evaluation (shortest valid table per point) x {valu_per_quad:g} '
              'vector-ALU instructions per quad')
     if interp is not None:
-        per_point = interp[2] if len(interp) > 2 else VALU_PER_POINT_INTERP
-        per_eval += interp[0] * per_point + interp[1] * VALU_PER_EPOCH_LOG
-        basis += (f' + {interp[0]:.0f} interpolated points x {per_point} + {interp[1]:.0f} log-space thermal '
-                  f'states x {VALU_PER_EPOCH_LOG}')
+        per_point = isa['point_lean'] if isa else float('nan')
+        per_state = (isa[interp[2] if len(interp) > 2 else 'state_lean']) if isa else float('nan')
+        per_eval += interp[0] * per_point + interp[1] * per_state
+        basis += (f' + {interp[0]:.0f} interpolated points x {per_point:.1f} + {interp[1]:.0f} log-space thermal '
+                  f'states x {per_state:g}')
     shipped = evals_per_launch * per_eval
     achieved = shipped / sec / 1e12
     out = {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'Tinstr/s', 'frac': achieved / peak,
            'kernel': kernel, 'kernel_ms': kern_ms, 'evaluations_per_launch': evals_per_launch,
-           'basis': basis + ' (ISA counts, tools/isa_count.py): the likelihood loops only, a lower bound of the '
-                            'instructions issued',
+           'basis': basis + (' (counted by the build in the ISA of the library that runs: csrc/liblcf_hip.isa.json, '
+                             'tools/isa_count.py): the likelihood loops only, a lower bound of the instructions issued'
+                             if isa_note is None else f' -- {isa_note}'),
            'algorithmic_speedup': evals_per_launch * alg_instr_per_eval / sec / 1e12 / peak,
            'algorithmic_speedup_note': "SURVEY 8d's instruction count of the reference's algorithm per second / the "
                                        'issue peak: exceeds 1 where the shipped algorithm needs fewer instructions '
@@ -505,8 +520,13 @@ def run_mcmc(args):
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=mode), dist,
                                      x0, args)
     kern_ms, used = half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7) if rank == 0 or world > 1 else (None, None)
-    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
+    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)       # the chain is stored, as the reference's run does
     value = n_walkers * args.steps / elapsed
+    device_ms = sampler.last_run_ms
+    t0 = time.perf_counter()
+    chain_shape = sampler.get_chain().shape                                # 48 bytes per walker and step over PCIe
+    download_s = time.perf_counter() - t0
+    elapsed_nochain = timed_run(sampler, dist, args.warmup, args.steps, None, store=False)
     coll = collective_info(sampler, dist, world)
     if coll is not None:
         coll['probe'] = probe
@@ -520,7 +540,7 @@ def run_mcmc(args):
         # the committed counters are those of the default configuration (k_solo, interpolated level); any other
         # kernel or table level has no PMC pass of its own and reports null
         pmc_tag = 'k_solo_mcmc' if (used, args.variant) == ('solo', 3) else f'k_{used}_v{args.variant}_mcmc'
-        roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, ALG_INSTR,
+        roof = roofline_block(name, kern_ms, per_rank // 2, quads, None, PEAK_FP64_TINSTR, ALG_INSTR,
                               ALG_BYTES, pmc_tag, waves_per_launch=(per_rank // 2) * 8,
                               interp=(n_interp, N_EPOCHS) if n_interp else None)
         out = {
@@ -535,7 +555,13 @@ def run_mcmc(args):
                        'band_sum_variant': args.variant,
                        'parallelism': f'walker-sharded x{world}' if world > 1 else 'single GPU'},
             'roofline': roof, 'collective': coll,
-            'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None,
+            'device_ms_per_step': device_ms / args.steps if world == 1 else None,
+            'chain': {'stored': True, 'shape': list(chain_shape),
+                      'note': 'value is the run that keeps its chain in HBM (the reference: emcee stores every step, '
+                              'fitting.py:144-148); below: the same steps without a chain, and with the chain also '
+                              'copied to the host afterwards (PCIe-inclusive, never the headline)',
+                      'value_without_chain': n_walkers * args.steps / elapsed_nochain,
+                      'value_with_chain_on_host': n_walkers * args.steps / (elapsed + download_s) if world == 1 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(lc)
@@ -618,9 +644,9 @@ def run_companion(args):
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
         name = {'solo': 'k_solo<8,1,true,4> (one 512-thread workgroup per proposal, its two halves take two of the four parts each)', 'fused': 'k_fused<8,1,true>',
                 'phases': 'k_step + k_points'}[used]
-        roof = roofline_block(name, kern_ms, per_rank // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr,
+        roof = roofline_block(name, kern_ms, per_rank // 2, quads, None, PEAK_FP64_TINSTR, alg_instr,
                               8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 8,
-                              interp=(n_interp, 1000, VALU_PER_POINT_INTERP_GENERAL) if n_interp else None)
+                              interp=(n_interp, 1000, 'log_lean') if n_interp else None)
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -672,12 +698,14 @@ def run_population(args):
     pop = PopulationSampler(problems, nw, seed=SEED, device=local_rank)
     for k in pop.indices:
         pop[k].engine.set_variant(args.variant)
+    for k in pop.indices:
+        pop[k].reserve_chain(args.steps)          # (the chains' device memory: allocated ahead of the timed steps)
     pop.run_mcmc(x0, args.warmup, store=False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    pop.run_mcmc(None, args.steps, store=False)
+    pop.run_mcmc(None, args.steps, store=True)    # every ensemble keeps its chain in HBM, as the reference's run does
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -693,7 +721,7 @@ def run_population(args):
                 'population-phases': 'k_step_multi + k_points_multi (the two launches of a half-step of all 32 '
                                      'transients of this GPU; the likelihood launch dominates)'}[used]
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
-        roof = roofline_block(name, pair_ms, 32 * nw // 2, quads, VALU_PER_QUAD_F64, PEAK_FP64_TINSTR, alg_instr, ALG_BYTES,
+        roof = roofline_block(name, pair_ms, 32 * nw // 2, quads, None, PEAK_FP64_TINSTR, alg_instr, ALG_BYTES,
                               'population' if (used, args.variant) == ('population', 3) else f'{used}_v{args.variant}',
                               interp=(n_interp, 100) if n_interp else None)
         out = {'metric': 'walker-steps/sec (population of independent ensembles)',

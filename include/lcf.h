@@ -151,8 +151,10 @@ int32_t lcf_engine_ndim(const lcf_engine* e);
 int64_t lcf_engine_npoints(const lcf_engine* e);
 /* Planck samples of one log-likelihood evaluation over the full tables: sum over points of K_filter. */
 int64_t lcf_engine_samples_per_eval(const lcf_engine* e);
-/* Select the band-sum variant: 0 = libm expm1 + divide over the full tables (reference-shaped), 1 = fused fast path
- * over the full tables, 2 = fused fast path over the compressed tables where valid (default when they are given). */
+/* Select the band-sum level: 0 = libm expm1 + divide over the full tables (reference-shaped), 1 = fused fast path
+ * over the full tables, 2 = fused fast path over the Gauss-compressed tables where valid, 3 = the interpolants of
+ * ln S_f(ln T) where a point's temperature is inside the range they are proved for, else level 2.  An engine starts
+ * at the highest level its problem gave tables for (3 with itab_*, else 2 with ctab_*, else 1). */
 lcf_status lcf_engine_set_variant(lcf_engine* e, int32_t variant);
 
 /* Model.log_likelihood (models.py:93-136) for a block of n walkers.  Host pointers. out[n]. */
@@ -185,6 +187,9 @@ void lcf_sampler_destroy(lcf_sampler* s);
 /* coords[n_walkers][n_dim] host; evaluates the initial log-posterior on the device. */
 lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords);
 lcf_status lcf_sampler_get_state(lcf_sampler* s, double* coords, double* log_prob);
+/* Device memory for the chain of a later run of n_steps steps with store_chain, allocated now instead of inside that
+ * run (emcee grows its backend inside run_mcmc, fitting.py:133-148; a caller that times a run reserves first). */
+lcf_status lcf_sampler_reserve_chain(lcf_sampler* s, int64_t n_steps);
 /* Red/blue colouring of each step.  RANDOM = emcee's randomize_split, generated on the device from (seed, step);
  * HOST = caller-provided perm[n_steps][n_walkers] int32 (the first half of each row is colour 0). */
 enum { LCF_SPLIT_IDENTITY = 0, LCF_SPLIT_RANDOM = 1, LCF_SPLIT_HOST = 2 };

@@ -583,8 +583,11 @@ __device__ __forceinline__ void powerlaw_log_state(const DevProblem& pb, double 
     const double eps1 = k[3], eps2 = k[4], alpha = k[2];
     const double lt = tlog(t);
     // (the exponential through the 2^(j/256) table: same arithmetic whether `et` points to LDS or memory)
+    // (argument clamped from above: beyond e^1100 the table exponential overflows to +inf through its ldexp, as libm's
+    // does -- an infinite argument, M_env = 0, would otherwise be inf - inf = NaN inside it, where the reference's
+    // exp(-inf) makes the luminosity 0)
     const double E = !(c3 == c3) ? 0.
-                     : LCF_TEXP ? exp_scaled<true>(fma(alpha, lt, c3) * kInvLn2N, et)
+                     : LCF_TEXP ? exp_scaled<true>(fmin(fma(alpha, lt, c3) * kInvLn2N, 1100. * kInvLn2N), et)
                                 : exp(fma(alpha, lt, c3));
     lL = fma(-2. * eps2, lt, c7) - E;
     u = fma(2. * eps1 - 0.5, lt, c6);

@@ -784,9 +784,21 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
     double S = 0.;
     if (Tk > 0. && Tk < kTmax) {
         const ExpTab et{exptab};
-        const TabSel<const double2*> ts{pb.tab, tab_slice(tab_off[2 * f], tab_off[2 * f + 1]),
-                                        tab_slice(ctab_off[2 * f], ctab_off[2 * f + 1]), 0, 1. / ctmin[f], 0.};
-        S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 1. / Tk, et);
+        // the interpolated level (the engine's default where it has the interpolants): ln S_f(ln T) inside the range the
+        // filter's interpolant is proved for -- a per-triple choice, a triple's result depends on nothing else
+        bool done = false;
+        if (VARIANT != 0 && pb.use_itab) {
+            const double x = (log(Tk) - pb.itab_u0) * pb.itab_inv_h;
+            if (x >= (double)pb.f_desc[f].r_min && x < (double)pb.itab_m) {
+                S = exp_scaled<false>(interp_log_band_sum(pb, -1, pb.f_desc[f].ioff, x) * kInvLn2N, et);
+                done = true;
+            }
+        }
+        if (!done) {
+            const TabSel<const double2*> ts{pb.tab, tab_slice(tab_off[2 * f], tab_off[2 * f + 1]),
+                                            tab_slice(ctab_off[2 * f], ctab_off[2 * f + 1]), 0, 1. / ctmin[f], 0.};
+            S = band_sum_at<VARIANT>(ts, pb.use_ctab != 0, 1. / Tk, et);
+        }
     }
     out[i] = r * r * S;
 }
@@ -3106,6 +3118,22 @@ lcf_status settle(lcf_sampler* s) {
 // Whatever changes the state on the device makes the host's copy stale.
 void invalidate_snapshot(lcf_sampler* s) { s->snap_enqueued = s->snap_valid = false; }
 
+// Device memory for the chain of a run of n_steps steps (kept until a longer run needs more).
+lcf_status reserve_chain(lcf_sampler* s, int64_t n_steps) {
+    DevSampler& ds = s->ds;
+    if (n_steps <= s->chain_cap) return LCF_OK;
+    LCF_HIP(hipStreamSynchronize(s->e->stream));
+    if (ds.chain) hipFree(ds.chain);
+    if (ds.chain_lp) hipFree(ds.chain_lp);
+    ds.chain = nullptr;
+    ds.chain_lp = nullptr;
+    s->chain_cap = 0;
+    LCF_HIP(hipMalloc((void**)&ds.chain, (size_t)n_steps * ds.n_walkers * ds.n_dim * sizeof(double)));
+    LCF_HIP(hipMalloc((void**)&ds.chain_lp, (size_t)n_steps * ds.n_walkers * sizeof(double)));
+    s->chain_cap = n_steps;
+    return LCF_OK;
+}
+
 // Start a run of n_steps steps: settle what the previous run left pending, size the chain and the draw blocks, and
 // enqueue the generation of the first block.  Nothing here waits for the device unless a buffer has to grow.
 // `need_slots`: the draw records carry each walker's slot in the previous half-step (every path except k_solo).
@@ -3132,17 +3160,8 @@ lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, in
     s->g_next += 2;
     s->g_run0 = s->g_next;
     ds.store_chain = store_chain ? 1 : 0;
-    if (store_chain && n_steps > s->chain_cap) {
-        LCF_HIP(hipStreamSynchronize(e->stream));
-        if (ds.chain) hipFree(ds.chain);
-        if (ds.chain_lp) hipFree(ds.chain_lp);
-        ds.chain = nullptr;
-        ds.chain_lp = nullptr;
-        s->chain_cap = 0;
-        LCF_HIP(hipMalloc((void**)&ds.chain, (size_t)n_steps * ds.n_walkers * ds.n_dim * sizeof(double)));
-        LCF_HIP(hipMalloc((void**)&ds.chain_lp, (size_t)n_steps * ds.n_walkers * sizeof(double)));
-        s->chain_cap = n_steps;
-    }
+    if (store_chain)
+        if (lcf_status st = reserve_chain(s, n_steps)) return st;
     if (perm && n_steps > 0) {
         // validate: every row must be a permutation of 0..n_walkers-1 (out-of-range ids would fault the GPU)
         std::vector<char> seen(ds.n_walkers);
@@ -3244,6 +3263,14 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
 }
 
 void lcf_sampler_destroy(lcf_sampler* s) { delete s; }
+
+lcf_status lcf_sampler_reserve_chain(lcf_sampler* s, int64_t n_steps) {
+    if (!s || n_steps < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
+    LCF_HIP(hipSetDevice(s->e->device));
+    if (s->ds.store_chain && s->run_steps > 0 && n_steps > s->chain_cap)
+        return fail(LCF_ERR_STATE, "the stored chain of the last run must be read (lcf_sampler_get_chain) before its buffer grows");
+    return reserve_chain(s, n_steps);
+}
 
 lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     if (!s || !coords) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");

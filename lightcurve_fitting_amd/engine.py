@@ -92,6 +92,7 @@ SIGNATURES = [
     ('lcf_population_run', C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                      _dp]),
     ('lcf_sampler_get_chain', C.c_int, [C.c_void_p, _dp, _dp]),
+    ('lcf_sampler_reserve_chain', C.c_int, [C.c_void_p, C.c_int64]),
     ('lcf_sampler_get_naccepted', C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ('lcf_sampler_last_run_ms', C.c_double, [C.c_void_p]),
     ('lcf_sampler_begin', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
@@ -477,6 +478,10 @@ class NativeSampler:
 
     def check(self):
         _check(self._lib.lcf_sampler_check(self._h))
+
+    def reserve_chain(self, n_steps):
+        """Allocate the device memory a stored run of n_steps steps needs now, instead of inside that run."""
+        _check(self._lib.lcf_sampler_reserve_chain(self._h, int(n_steps)))
 
     def get_chain(self):
         nsteps, store = self._last

@@ -519,12 +519,13 @@ class Blackbody(Model):
         return super()._eval_engine(t_in, f, True)
 
 
-def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0.):
+def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0., variant=None):
     """Band-averaged L_nu of blackbodies through filters (models.py:1131-1165).
 
     Pointwise when ``T`` is 1-D with one entry per filter, else every filter for every (T, R): result shape
     ``(nfilters,) + T.shape``.  ``ebv``: one E(B-V) for the whole call (the reddening goes into the table weights at
-    pack time); per-walker reddening inside a fit is ``ShockCooling3``'s job."""
+    pack time); per-walker reddening inside a fit is ``ShockCooling3``'s job.  ``variant``: the band-sum level
+    (``Engine.set_variant``; None = the engine's default, the interpolants of ln S(ln T))."""
     if np.ndim(ebv) != 0:
         raise NotImplementedError('blackbody_to_filters takes one scalar E(B-V) per call')
     T = np.array(T, dtype=np.float64)
@@ -540,8 +541,11 @@ def blackbody_to_filters(filters, T, R, z=0., cutoff_freq=np.inf, ebv=0.):
     else:
         tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
         ctab = (tabs.coff, tabs.ca, tabs.cw, tabs.ctmin)
+    itab = None if ebv else (tabs.icoef, tabs.itmin, tabs.iu0, tabs.ih)
     eng = _eng.Engine(_eng.MODEL_BLACKBODY, 2, [], np.zeros(1), np.zeros(1), np.ones(1), np.zeros(1, dtype=np.int32),
-                      tabs.off, tabs.a, tabs.w, ctab=ctab)  # (pointwise kernel: cool level only)
+                      tabs.off, tabs.a, tabs.w, ctab=ctab, itab=itab)  # (pointwise kernel: interpolants + cool level)
+    if variant is not None:
+        eng.set_variant(variant)
     try:
         if T.ndim == 1 and len(T) == len(filts):
             return eng.blackbody_to_filters(idx, T, R)

@@ -284,9 +284,11 @@ class EnsembleSampler:
         self._peers = None  # True once the mailboxes are connected, False if unavailable
         self._comm = None  # NativeComm once created, False if unavailable
         self._steps_done = 0   # RNG step counter: never reset, so burn-in and sampling use disjoint streams
-        self._chain = np.empty((0, nwalkers, ndim))
-        self._lp = np.empty((0, nwalkers))
+        self._chain_host = np.empty((0, nwalkers, ndim))
+        self._lp_host = np.empty((0, nwalkers))
+        self._chain_on_device = 0   # steps of the last stored run whose chain is still in HBM only
         self._naccepted = np.zeros(nwalkers, dtype=np.int64)
+        self._acc_seen = None   # the native acceptance counts as of the last finished run
         self._nsteps_counted = 0
         self._state = None
 
@@ -400,13 +402,39 @@ class EnsembleSampler:
     # --- emcee surface -------------------------------------------------------------------------------------------
     def reset(self):
         """Forget the stored chain (not the RNG position), like ``emcee.EnsembleSampler.reset``."""
-        self._chain = np.empty((0, self.nwalkers, self.ndim))
-        self._lp = np.empty((0, self.nwalkers))
+        self._chain_host = np.empty((0, self.nwalkers, self.ndim))
+        self._lp_host = np.empty((0, self.nwalkers))
+        self._chain_on_device = 0
         self._naccepted[:] = 0
         self._nsteps_counted = 0
 
+    def reserve_chain(self, nsteps):
+        """Allocate the device memory of a stored run of ``nsteps`` steps ahead of it (a timed run then allocates
+        nothing)."""
+        self._collect_chain()
+        self._native.reserve_chain(nsteps)
+
+    def _collect_chain(self):
+        """Bring the last stored run's chain to the host (once)."""
+        if self._chain_on_device:
+            chain, lp = self._native.get_chain()
+            self._chain_host = np.concatenate([self._chain_host, chain])
+            self._lp_host = np.concatenate([self._lp_host, lp])
+            self._chain_on_device = 0
+
+    @property
+    def _chain(self):
+        self._collect_chain()
+        return self._chain_host
+
+    @property
+    def _lp(self):
+        self._collect_chain()
+        return self._lp_host
+
     def _prepare(self, initial_state, skip_initial_state_check=False):
         """Validate and upload the starting positions (or continue from the stored state)."""
+        self._collect_chain()   # (the next run reuses the device's chain buffer)
         if initial_state is not None:
             coords = np.array(initial_state[0] if isinstance(initial_state, tuple) else initial_state,
                               dtype=np.float64)
@@ -419,10 +447,12 @@ class EnsembleSampler:
                                  'Make sure that your walkers are linearly independent for the best performance')
             self._native.set_state(coords)
             self._acc0 = np.zeros(self.nwalkers, dtype=np.int64)
+            self._acc_seen = None
         elif self._state is None:
             raise ValueError('Cannot have `initial_state=None` if run_mcmc has never been called.')
         else:
-            self._acc0 = self._native.naccepted()
+            # (the counts the last run left: remembered by _finish -- nothing but a run changes them)
+            self._acc0 = self._acc_seen if self._acc_seen is not None else self._native.naccepted()
         if initial_state is not None and np.any(np.isnan(self._native.get_state()[1])):
             raise ValueError('Probability function returned NaN')
         self._in_flight = False
@@ -468,10 +498,11 @@ class EnsembleSampler:
             self._in_flight = False
         self._steps_done += nsteps
         if store and nsteps:
-            chain, lp = self._native.get_chain()
-            self._chain = np.concatenate([self._chain, chain])
-            self._lp = np.concatenate([self._lp, lp])
-        self._naccepted += self._native.naccepted() - self._acc0
+            # The chain of a run stays in HBM until somebody reads it (or the next run needs the buffer): a run returns
+            # when the device has finished, not when 80 bytes per walker and step have crossed PCIe.
+            self._chain_on_device = nsteps
+        self._acc_seen = self._native.naccepted()
+        self._naccepted += self._acc_seen - self._acc0
         self._nsteps_counted += nsteps
         x, lp = self._native.get_state()
         self._state = State(x, lp, None)
@@ -512,7 +543,7 @@ class EnsembleSampler:
 
     @property
     def iteration(self):
-        return len(self._chain)
+        return len(self._chain_host) + self._chain_on_device
 
     @property
     def acceptance_fraction(self):

@@ -50,6 +50,26 @@ def _run(eng, nwalkers, seed, x0, nsteps, kernel, split='random'):
     return used, chain, lp, s.naccepted(), s
 
 
+def test_states_outside_the_interpolants_take_the_general_path():
+    """Half of the walkers start with an explosion time BEHIND the first epochs (negative phases: no log-space state) and
+    every proposal that mixes such a walker with another one lands anywhere in between: waves of the model-specialised
+    half-step kernel leave their straight-line path for the out-of-line general one, waves of the generic kernels fall
+    back from the interpolants to the sample tables -- one chain for all kernels, and the oracle's."""
+    pb, eng = _multiband()
+    rng = np.random.default_rng(11)
+    x0 = pb['truth'] * (1 + 0.05 * rng.standard_normal((64, 5)))
+    x0[::2, 4] = rng.uniform(0.405, 0.49, 32)      # epochs start at 0.4 d; the prior allows up to 0.5
+    assert np.any(pb['t'].min() < x0[:, 4])
+    runs = {k: _run(eng, 64, 5, x0, 6, k) for k in ('auto', 'fused', 'phases')}
+    assert runs['auto'][0] == 'solo'
+    for k in ('fused', 'phases'):
+        assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][2], runs[k][2])
+    ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 5)
+    assert relerr(runs['auto'][1], ref) < 1e-9 and relerr(runs['auto'][2], ref_lp) < 1e-9
+    assert np.array_equal(runs['auto'][3], ref_acc)
+    assert np.any(runs['auto'][1][-1][:, 4] > pb['t'].min())   # (walkers behind the first epoch survive to the end)
+
+
 @pytest.mark.parametrize('nwalkers', [40, 41])
 def test_three_kernels_one_chain(nwalkers):
     pb, eng = _multiband()

@@ -14,7 +14,9 @@ TOL = 1e-11
 VARIANTS = {'n15': dict(n=1.5), 'n3': dict(n=3.), 'rw': dict(RW=True), 'n3rw': dict(n=3., RW=True)}
 
 
-@pytest.fixture(params=[2, 1, 0], ids=['gauss', 'fast', 'libm'])
+# band-sum levels (lcf_engine_set_variant): 3 = the interpolants of ln S(ln T), what an engine starts with and what every
+# bench line times; 2 = Gauss-compressed tables; 1 = full tables, fused exponentials; 0 = libm, shaped like the reference
+@pytest.fixture(params=[3, 2, 1, 0], ids=['interp', 'gauss', 'fast', 'libm'])
 def variant(request):
     return request.param
 
@@ -36,14 +38,14 @@ def test_blackbody_to_filters_primitive(variant):
     names = [str(x) for x in p['synth/names']]
     for z in (0., 0.002, 0.5):
         # every filter x every (T, R) -> dense branch (models.py:1163-1164)
-        got = M.blackbody_to_filters(names, p['synth/T'], p['synth/R'], z=z)
+        got = M.blackbody_to_filters(names, p['synth/T'], p['synth/R'], z=z, variant=variant)
         assert relerr(got, p[f'synth/z{z}']) < TOL
-    got = M.blackbody_to_filters(names[:6], p['synth/T'], p['synth/R'], z=0.01, cutoff_freq=300.)
+    got = M.blackbody_to_filters(names[:6], p['synth/T'], p['synth/R'], z=0.01, cutoff_freq=300., variant=variant)
     assert relerr(got, p['synth/cutoff300_z0.01']) < TOL
-    got = M.blackbody_to_filters(names[:6], p['synth/extreme_T'], np.full(7, 2.))
+    got = M.blackbody_to_filters(names[:6], p['synth/extreme_T'], np.full(7, 2.), variant=variant)
     assert relerr(got, p['synth/extreme']) < TOL  # exp overflow -> 0, T <= 0 -> 0
     # pointwise branch (models.py:1161-1162) and KA-2
-    got = M.blackbody_to_filters(list('UBVgri'), np.full(6, 12.), np.full(6, 3.), z=0.002)
+    got = M.blackbody_to_filters(list('UBVgri'), np.full(6, 12.), np.full(6, 3.), z=0.002, variant=variant)
     assert relerr(got, [5.3340427714584846e+19, 5.5889452729878102e+19, 5.2231143459679003e+19,
                         5.5347843094141714e+19, 4.8700621798754804e+19, 4.1267907544148402e+19]) < TOL
     with pytest.raises(Exception, match='same shape'):
