@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 6
+#define LCF_ABI_VERSION 7
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -318,12 +318,16 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
 /* ---- per-epoch blackbody SED likelihood (bolometric.py:154-164: spectrum_mcmc's inner log_posterior) --------- */
 /* For every epoch e, observations ep_off[e] .. ep_off[e+1]-1 (filter index, luminosity density y, uncertainty dy);
  * for every candidate (T [kK], R [1000 Rsun][, sigma]) of that epoch the Gaussian log-likelihood of the band-averaged
- * blackbody [f.synthesize(planck_fast, T, R) for f in filters].  precision 0 = float64, 1 = float32 arithmetic. */
+ * blackbody [f.synthesize(planck_fast, T, R) for f in filters].  precision 0 = float64 over the band tables sample by
+ * sample, 1 = float32 over the band tables, 2 = float64 through the interpolants of ln S_f(ln T) where a candidate's
+ * temperature is inside their proved range and over the band tables where it is not (0 when no interpolants were given). */
 typedef struct lcf_sed lcf_sed;
-/* ctab_*: optional Gauss-compressed companions of the band tables (all NULL = none), as in lcf_problem. */
+/* ctab_*: optional Gauss-compressed companions of the band tables (all NULL = none), itab_*: optional interpolants of
+ * ln S_f(ln T) (itab_coef NULL = none); both as in lcf_problem. */
 lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const double* tab_a, const double* tab_w,
                           const int32_t* ctab_off, const double* ctab_a, const double* ctab_w,
-                          const double* ctab_tmin, int32_t device, lcf_sed** out);
+                          const double* ctab_tmin, const double* itab_coef, const double* itab_tmin, int32_t itab_m,
+                          double itab_u0, double itab_h, int32_t device, lcf_sed** out);
 void lcf_sed_destroy(lcf_sed* s);
 lcf_status lcf_sed_set_observations(lcf_sed* s, int64_t n_epochs, const int32_t* ep_off, const int32_t* filt_idx,
                                     const double* y, const double* dy);

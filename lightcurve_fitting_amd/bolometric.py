@@ -65,7 +65,9 @@ class SpectrumLikelihood:
         lookup = {f: i for i, f in enumerate(uniq)}
         tabs = PackedTables(uniq, z=z, cutoff_freq=cutoff_freq)
         self.engine = _eng.SedEngine(tabs.off, tabs.a, tabs.w, device=device,
-                                     ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin))
+                                     ctab=(tabs.coff, tabs.ca, tabs.cw, tabs.ctmin),
+                                     itab=tabs.interpolants(below=10))   # from 0.94 kK: the priors start at 1 kK
+        self.itab_tmin = tabs.interpolants(below=10)[1]
         off = np.concatenate([[0], np.cumsum([len(fl) for fl in filts])])
         idx = np.array([lookup[f] for fl in filts for f in fl], dtype=np.int32)
         y = np.concatenate([np.asarray(e[1], dtype=float) for e in epochs]) if len(epochs) else np.zeros(0)
@@ -75,13 +77,18 @@ class SpectrumLikelihood:
         self.samples_per_candidate = np.array([sum(tabs.off[lookup[f] + 1] - tabs.off[lookup[f]] for f in fl)
                                                for fl in filts])
 
+    #: arithmetic of the device kernel: 'f64' = float64 through the interpolants of ln S_f(ln T) (the light-curve
+    #: engine's default level; sample tables outside their range), 'f64-tables' = float64 sample by sample (the
+    #: reference's own sum), 'f32' = float32 sample by sample (BASELINE configs[3] as specified)
+    PRECISIONS = {'f64': 2, 'f64-tables': 0, 'f32': 1}
+
     def __call__(self, candidates, sigma_type='relative', precision='f64', compressed=True):
         """``candidates``: (n_epochs, n_cand, 2|3) of (T, R[, sigma]) -> log-likelihoods (n_epochs, n_cand).
         ``compressed``: use the Gauss-compressed band tables where they are valid (same sums to 2e-14)."""
         if sigma_type not in ('relative', 'absolute'):
             raise Exception('sigma_type must either be "relative" or "absolute"')
         st = _eng.SIGMA_RELATIVE if sigma_type == 'relative' else _eng.SIGMA_ABSOLUTE
-        return self.engine.log_likelihood(candidates, st, {'f64': 0, 'f32': 1}[precision], compressed)
+        return self.engine.log_likelihood(candidates, st, self.PRECISIONS[precision], compressed)
 
 
 def spectrum_log_likelihood(filters, y, dy, T, R, z=0., sigma=None, sigma_type='relative', precision='f64'):

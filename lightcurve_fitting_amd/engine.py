@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 6
+LCF_ABI_VERSION = 7
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -122,7 +122,8 @@ SIGNATURES = [
     ('lcf_sampler_board_connect', C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     ('lcf_sampler_run_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sampler_run_rows_async', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
-    ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, _ip, _dp, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    ('lcf_sed_create', C.c_int, [C.c_int32, _ip, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, C.c_int32, C.c_double,
+                                 C.c_double, C.c_int32, C.POINTER(C.c_void_p)]),
     ('lcf_sed_destroy', None, [C.c_void_p]),
     ('lcf_sed_set_observations', C.c_int, [C.c_void_p, C.c_int64, _ip, _ip, _dp, _dp]),
     ('lcf_sed_log_likelihood', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, _dp,
@@ -570,7 +571,7 @@ class SedEngine:
     """Per-epoch blackbody SED likelihood on the device (``lcf_sed_*``): band tables are fixed at creation,
     observations are set per batch of epochs, candidates are evaluated per call."""
 
-    def __init__(self, tab_off, tab_a, tab_w, device=0, ctab=None):
+    def __init__(self, tab_off, tab_a, tab_w, device=0, ctab=None, itab=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         off, a, w = _i32(tab_off), _f64(tab_a), _f64(tab_w)
@@ -579,7 +580,15 @@ class SedEngine:
         else:
             cx = [_i32(ctab[0]), _f64(ctab[1]), _f64(ctab[2]), _f64(ctab[3])]
             cargs = (_ptr(cx[0], _ip), _ptr(cx[1]), _ptr(cx[2]), _ptr(cx[3]))
-        _check(self._lib.lcf_sed_create(len(off) - 1, _ptr(off, _ip), _ptr(a), _ptr(w), *cargs, int(device),
+        if itab is None:   # (coef[n_filters, m, 8], tmin[n_filters], u0, h): interpolants of ln S(ln T)
+            iargs = (None, None, 0, 0., 0.)
+        else:
+            ic, it = _f64(itab[0]), _f64(itab[1])
+            if ic.ndim != 3 or ic.shape[0] != len(off) - 1 or ic.shape[2] != 8 or it.shape != (len(off) - 1,):
+                raise ValueError('inconsistent interpolants')
+            iargs = (_ptr(ic), _ptr(it), ic.shape[1], float(itab[2]), float(itab[3]))
+        self.has_interpolants = itab is not None
+        _check(self._lib.lcf_sed_create(len(off) - 1, _ptr(off, _ip), _ptr(a), _ptr(w), *cargs, *iargs, int(device),
                                         C.byref(self._h)))
         self.n_epochs = 0
         self.last_kernel_ms = 0.

@@ -526,6 +526,25 @@ class PackedTables:
                 if res is not None:
                     self.icoef[i], self.itmin[i], self.ibound[i] = res
 
+    def interpolants(self, below=0):
+        """``(coef[n_filters, m, 8], t_min[n_filters], u0, h)`` as the engines take them.  ``below`` > 0: the table
+        starts that many intervals BELOW ``INTERP_TMIN`` (same interval width, so the intervals above are the engine's
+        own; 10 intervals reach down to 0.94 kK: the per-epoch SED engine's candidates come from priors that start at
+        1 kK, bolometric.py:729).  Every filter's part below is proved like the rest, or its ``t_min`` says where it holds."""
+        if not below:
+            return self.icoef, self.itmin, self.iu0, self.ih
+        t_lo = float(np.exp(self.iu0 - below * self.ih))
+        m = self.im + below
+        coef = np.zeros((len(self.filters), m, INTERP_DEGREE + 1))
+        tmin = np.full(len(self.filters), np.inf)
+        if np.isfinite(self.itmin).any():
+            for i in range(len(self.filters)):
+                res = interp_planck_table(self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]],
+                                          t_lo=t_lo, t_hi=float(np.exp(self.iu0 + self.im * self.ih)), m=m)
+                if res is not None:
+                    coef[i], tmin[i] = res[0], res[1]
+        return coef, tmin, float(np.log(t_lo)), self.ih
+
     def index(self, f):
         return self.filters.index(as_filter(f))
 

@@ -16,14 +16,19 @@ def _epochs(g):
              g['sed/dy'][off[e]:off[e + 1]]) for e in range(len(off) - 1)]
 
 
-def test_sed_float64_parity():
+@pytest.mark.parametrize('precision', ['f64', 'f64-tables'])
+def test_sed_float64_parity(precision):
+    """Both float64 modes against the reference's numbers: 'f64' = the interpolants of ln S(ln T) (the default, the one
+    the bench line reports; candidates outside their range finish over the sample tables), 'f64-tables' = sample by
+    sample.  north_star asks 1e-6; both are held to 1e-11."""
     g = golden('sed')
     like = B.SpectrumLikelihood(_epochs(g), z=float(g['sed/z']))
+    assert like.engine.has_interpolants
     c = g['sed/cand']
     for comp in (True, False):  # Gauss-compressed and full band tables
-        assert relerr(like(c[:, :, :2], compressed=comp), g['sed/ll']) < 1e-11
-        assert relerr(like(c, 'relative', compressed=comp), g['sed/ll_rel']) < 1e-11
-        assert relerr(like(c, 'absolute', compressed=comp), g['sed/ll_abs']) < 1e-11
+        assert relerr(like(c[:, :, :2], precision=precision, compressed=comp), g['sed/ll']) < 1e-11
+        assert relerr(like(c, 'relative', precision, compressed=comp), g['sed/ll_rel']) < 1e-11
+        assert relerr(like(c, 'absolute', precision, compressed=comp), g['sed/ll_abs']) < 1e-11
     with pytest.raises(Exception, match='sigma_type'):
         like(c, 'bogus')
     with pytest.raises(ValueError, match='shape'):
@@ -71,6 +76,13 @@ def test_sed_grid_at_config4_width_against_oracle():
     m = ('Blackbody', type('Z', (), {'z': 0.})())
     ref = np.array([O.log_likelihood(m, None, bands, y, dy, cand[e].T) for e, (_, y, dy) in enumerate(epochs)])
     assert relerr(got, ref) < 1e-11
+    assert relerr(like(cand, precision='f64-tables'), ref) < 1e-11
+    assert np.any(cand[..., 0] < 2.)          # (some candidates are colder than the interpolants' range: k_sed_rest)
+    # candidates with a fitted sigma, and an epoch count that is not a multiple of anything
+    cand3 = np.concatenate([cand, rng.uniform(0., 2., (n_ep, n_c, 1))], axis=-1)[:37, :101]
+    like37 = B.SpectrumLikelihood(epochs[:37], z=0.)
+    for st in ('relative', 'absolute'):
+        assert relerr(like37(cand3, st), like37(cand3, st, 'f64-tables')) < 1e-11
     f32 = like(cand, precision='f32')
     assert relerr(f32, got) < 1e-4
     assert like.engine.last_kernel_ms > 0.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The unprofiled bench lines of profiles/<tag>_bench_*.json alone (after a change of bench.py that leaves the kernels,
-# and with them the PMC summaries of tools/collect_profiles.sh, as they are).   bash tools/bench_lines.sh r02
-TAG=${1:-r02}
+# and with them the PMC summaries of tools/collect_profiles.sh, as they are).   bash tools/bench_lines.sh r03
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/lines_$TAG
 mkdir -p $OUT
