@@ -128,8 +128,30 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), LCF_BENCH_SPAWNED='1')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
-    return max(abs(c) for c in codes)
+    # The ranks are polled, not waited for one by one: as soon as one exits non-zero -- or the deadline passes -- the
+    # others (which may sit in a collective that will never complete) are ended and the bench fails, instead of hanging.
+    deadline = time.monotonic() + float(os.environ.get('LCF_BENCH_DEADLINE_S', '1500'))
+    worst = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if all(c is not None for c in codes):
+            return max([worst] + [abs(c) for c in codes])
+        if failed or time.monotonic() > deadline:
+            worst = max([abs(c) for c in failed] + [124])
+            time.sleep(2.)                        # (a rank that is about to fail the same way gets to say so)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10.)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print(f'bench.py: rank exit codes {[p.poll() for p in procs]}'
+                  + (' (deadline passed)' if not failed else ''), file=sys.stderr)
+            return worst
+        time.sleep(0.05)
 
 
 def init_distributed(args):
@@ -230,43 +252,14 @@ def quiet_interpreter():
 
 
 def pick_collective(make_sampler, dist, x0, args):
-    """N > 1: the sampler that runs the timed steps.  `--collective auto` tries the peer mailboxes and the all-gather
-    for a few untimed steps each: a driver that raises on any rank (its waits are bounded), that silently fell back, or
-    that leaves the ranks with different replicas of the ensemble is out; of the rest the faster one is taken.  Nothing
-    collective happens inside the try blocks, so a failure on one rank cannot leave the others waiting."""
+    """N > 1: the sampler that runs the timed steps.  `--collective auto` = the library's own probe
+    (lightcurve_fitting_amd.sampler.probe_collectives: what EnsembleSampler(collective=None) runs on its first multi-rank
+    run), here with the bench's sampler factory so that the selected sampler itself runs the timed steps and the report
+    goes into the line."""
     if dist is None or args.collective != 'auto':
         return make_sampler(None if dist is None else args.collective), None
-    import torch
-    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-    probe_steps = max(10, min(50, args.warmup * 4))
-    weights = np.cos(np.arange(x0.size, dtype=np.float64)).reshape(x0.shape)
-    report, best = {}, None
-    for mode in ('rows', 'peers', 'allgather'):
-        seconds, checksum, why, s = float('inf'), 0., None, None
-        try:
-            s = make_sampler(mode)
-            s.run_mcmc(x0, 5, store=False)
-            t0 = time.perf_counter()
-            state = s.run_mcmc(None, probe_steps, store=False)   # (returns after the device has finished)
-            seconds = time.perf_counter() - t0
-            if (mode == 'peers' and not s._peers) or (mode == 'rows' and not s._boards):
-                seconds, why = float('inf'), 'the peer memory could not be connected'
-            checksum = float(np.sum(np.asarray(state[0]) * weights))
-        except Exception as exc:  # noqa: BLE001
-            seconds, why = float('inf'), f'{type(exc).__name__}: {exc}'[:200]
-        agg = torch.tensor([seconds if np.isfinite(seconds) else 1e30, checksum, -checksum], dtype=torch.float64, device=dev)
-        dist.all_reduce(agg, op=dist.ReduceOp.MAX)
-        worst, hi, lo = float(agg[0]), float(agg[1]), -float(agg[2])
-        ok = worst < 1e29 and hi == lo
-        report[mode] = {'ok': ok, 'ms_per_step': 1e3 * worst / probe_steps if worst < 1e29 else None,
-                        'replicas_agree': hi == lo, 'note': why}
-        if ok and (best is None or worst < best[0]):
-            best = (worst, mode, s)
-    if best is None:
-        raise RuntimeError(f'no multi-GPU driver completed its probe: {report}')
-    report['selected'] = best[1]
-    report['probe_steps'] = probe_steps
-    return best[2], report
+    from lightcurve_fitting_amd.sampler import probe_collectives
+    return probe_collectives(make_sampler, dist, x0, probe_steps=max(10, min(50, args.warmup * 4)))
 
 
 def collective_info(sampler, dist, world):

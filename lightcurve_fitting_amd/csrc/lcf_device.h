@@ -54,8 +54,13 @@ struct FiltDesc {
     float r_min;   // interval coordinate (ln T - itab_u0) / h from which the filter's interpolant is proved; +inf: none
     int ioff;      // its coefficients in the interpolant array, in doubles
     double inv_tmin, inv_tmin2;  // 0 = that level does not exist
+    // companion-shocking models: which parameters are the filter's factors (models.py:909-917), -1 = none.  Here, next
+    // to the rest of what a point reads about its filter: from the staged copy these are LDS reads, from three separate
+    // arrays they were three dependent scalar loads per point.
+    int kpar, spar, dtpar, pad;
 };
-static_assert(sizeof(FiltDesc) == 48, "three double2 per filter in LDS");
+constexpr int kFdD2 = 4;   // double2 entries per descriptor
+static_assert(sizeof(FiltDesc) == 16 * kFdD2, "whole 16-byte entries per filter in LDS");
 
 struct DevProblem {
     int model, n_points, n_chunks, n_filters;
@@ -89,6 +94,10 @@ struct DevProblem {
     double consts[12];
     double log_norm_const;  // sum_i ln(2 pi dy_i^2), used when there is no sigma parameter
     double knot_inv_h;      // 1 / spacing of the spline knots when they are equally spaced (to 1e-9), else 0
+    // Template splines whose knots are EXACTLY k0 + i h in float64 (the SiFTO template: integer days): the interval of an
+    // argument is computed, not searched, and no knot is read.  knot_h = 0: not such a spline.
+    double knot0, knot_last, knot_h;
+    int n_spl_lds, pad6;    // doubles of `spl` staged in LDS behind the interpolants (all of it, or 0)
     double sigma_unit_abs;  // median(dy)
     // points, ordered by (part, filter)
     const double* t;
@@ -107,9 +116,6 @@ struct DevProblem {
     int stage_n16, pad5;         // its length in 16-byte units (the exp table and its pad only when !tab_in_lds)
     const double2* tab;  // (a_k, W_k)
     const double* tab_ext;  // ShockCooling3: 0.4 log2(10) A_k / E(B-V) per table sample (0 for padding), else null
-    const int* f_kpar;
-    const int* f_spar;
-    const int* f_dtpar;
     const double* knots;
     const double* spl;  // [n_filters][n_knots-1][4]
     const PriorDev* priors;
@@ -451,6 +457,18 @@ __device__ inline double spline_eval(const double* __restrict__ knots, int nk, c
     const double dx = x - knots[lo];
     const double* q = coef + 4 * lo;
     return fma(fma(fma(q[0], dx, q[1]), dx, q[2]), dx, q[3]);
+}
+
+// The same for knots that are exactly k0 + i h (DevProblem::knot_h > 0), coefficients at `coef` (the filter's, any
+// address space): no knot is read, the interval comes from one multiplication.  An argument within a rounding of a knot may
+// land in the neighbouring interval with dx = -1e-16 or h + 1e-16: the two cubics agree there to the third order.
+template <class CoefPtr>
+__device__ __forceinline__ double spline_eval_uniform(const DevProblem& pb, CoefPtr coef, double x) {
+    if (!(x >= pb.knot0 && x <= pb.knot_last)) return 0.;
+    const int lo = min(max((int)((x - pb.knot0) * pb.knot_inv_h), 0), pb.n_knots - 2);
+    const double dx = x - fma((double)lo, pb.knot_h, pb.knot0);
+    const double2 q01 = coef[2 * lo], q23 = coef[2 * lo + 1];
+    return fma(fma(fma(q01.x, dx, q01.y), dx, q23.x), dx, q23.y);
 }
 
 // Temperature [kK], its reciprocal, and the factor `pref` such that  L_nu = pref * S(T)  (pref = R_bb^2), for one

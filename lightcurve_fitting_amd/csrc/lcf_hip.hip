@@ -169,7 +169,7 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
                                      const FiltDesc* fdesc, const ExpTab et, double invT, double pref, int itab_at) {
     const int model = MODEL ? MODEL : pb.model;
     double S = 0., yfit;
-    const double2* fd = reinterpret_cast<const double2*>(fdesc) + 3 * filt;  // the filter's descriptor: three 16-byte reads
+    const double2* fd = reinterpret_cast<const double2*>(fdesc) + kFdD2 * filt;  // the filter's descriptor: 16-byte reads
     // Log-space state (x = ln T > 0, pref = ln R_bb^2; see thermal_state_log): the interpolant if every point of the
     // wave is inside its filter's proved range -- a per-wave choice, like the fast / safe band sums, so that a walker's
     // result never depends on how walkers are batched -- else the sample tables after one exponential each.
@@ -224,12 +224,26 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     if (!by_table) yfit = (pref != pref) ? pref : pref * S;
     if (model == kShockCooling3) yfit *= c[5];  // models.py:495
     if (model >= kCompanion && model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
-        const int kp = pb.f_kpar[filt], sp = pb.f_spar[filt], dp = pb.f_dtpar[filt];
+        const long long ks = __double_as_longlong(fd[3].x);   // {kpar, spar} and dtpar of the filter's descriptor
+        const int kp = (int)ks, sp = (int)(ks >> 32), dp = (int)__double_as_longlong(fd[3].y);
         const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
         const double sfac = sp >= 0 ? p[sp] : 1.;
         const double dt = dp >= 0 ? p[dp] : 0.;
         const double x = (t_in - c[3] - dt) / c[4];
-        const double tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x, pb.knot_inv_h);
+        double tmpl;
+        if (pb.knot_h > 0.) {   // integer-day knots: interval computed; coefficients from LDS where they are staged
+            extern __shared__ __align__(16) unsigned char smem[];
+            const int row0 = filt * (pb.n_knots - 1) * 2;   // double2 entries in front of the filter's
+            if (STAGED && pb.n_spl_lds > 0) {
+                const int spl_at = (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2) +
+                                         pb.n_itab_lds * sizeof(double));
+                tmpl = spline_eval_uniform(pb, reinterpret_cast<const double2*>(smem + spl_at) + row0, x);
+            } else {
+                tmpl = spline_eval_uniform(pb, reinterpret_cast<const double2*>(pb.spl) + row0, x);
+            }
+        } else {
+            tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x, pb.knot_inv_h);
+        }
         yfit = yfit * kfac + tmpl * sfac;
     }
     return yfit;
@@ -572,7 +586,7 @@ __device__ inline void stage_tables(const DevProblem& pb, double* __restrict__ e
         for (int k = t; k < kExpTabSize; k += nt) exptab[k] = pb.exp2tab[k];
         double2* lfd = ltab + pb.n_lds_tab;   // filter descriptors (48 B = 3 double2 each) behind the tables
         const double2* gfd = reinterpret_cast<const double2*>(pb.f_desc);
-        for (int k = t; k < 3 * pb.n_filters; k += nt) lfd[k] = gfd[k];
+        for (int k = t; k < kFdD2 * pb.n_filters; k += nt) lfd[k] = gfd[k];
         for (int k = t; k < pb.n_lds_tab; k += nt) {
             double2 aw = pb.tab[k];
             aw.y *= exp2(-ebv * pb.tab_ext[k]);
@@ -726,7 +740,7 @@ __device__ inline void points_body(const DevProblem& pb, int bid, int w_lo, int 
     const FiltDesc* fdesc = LDS_TAB ? reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab) : pb.f_desc;
     // byte offset of the staged interpolants in the dynamic LDS (behind the tables and descriptors), or -1
     const int itab_at = (LDS_TAB && pb.n_itab_lds > 0)
-                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2)) : -1;
     if constexpr (MODE == 0 && THERM) {
         // (the thermal states are the lanes' own: k_thermal is not launched for the likelihood)
         const double term = epochs_loop<VARIANT, LDS_TAB>(pb, part, P + (size_t)w * pb.n_dim, c, tbase, fdesc, ExpTab{exptab},
@@ -856,7 +870,19 @@ struct DevSampler {
     unsigned long long* board;
     unsigned long long* peer_board[kMaxPeers];
     int n_board_ranks, board_rank;
+    // Bound of every wait for another rank (mailbox entries, board rows, progress words), in ticks of the 100 MHz wall
+    // clock: peer_wait_ticks().  A rank's stream holds only a few ms of launches, so a host that stalls longer than
+    // this on ONE rank ends the run on ALL of them -- the default is therefore seconds, not the 0.5 s of round 2.
+    unsigned long long wait_ticks;
 };
+
+// LCF_PEER_WAIT_S (seconds, default 5; the tests of the bounded waits set 0.5)
+unsigned long long peer_wait_ticks() {
+    double sec = 5.;
+    if (const char* env = std::getenv("LCF_PEER_WAIT_S")) sec = std::atof(env);
+    if (!(sec > 0.)) sec = 5.;
+    return (unsigned long long)(std::min(sec, 600.) * 1e8);
+}
 
 // One float64 as two 8-byte granules {32 data bits, 32-bit generation tag}: an 8-byte store is the largest that
 // arrives whole, so a reader that sees the tag of the generation it waits for in both granules has the value -- no
@@ -874,7 +900,7 @@ __device__ inline void mbox_post(const DevSampler& sm, long long g, int slot, in
         }
 }
 
-// The value of generation g, once it has arrived; every lane's wait is bounded (0.5 s of the 100 MHz wall clock): a
+// The value of generation g, once it has arrived; every lane's wait is bounded (DevSampler::wait_ticks of the 100 MHz wall clock): a
 // peer that never delivers ends the run with an error instead of hanging the device.
 __device__ inline double mbox_take(const DevSampler& sm, long long g, int slot, int col, int stride) {
     const unsigned long long tag = (unsigned long long)(uint32_t)g;
@@ -885,7 +911,7 @@ __device__ inline double mbox_take(const DevSampler& sm, long long g, int slot, 
         const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((a >> 32) == tag && (b >> 32) == tag)
             return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
-        if (wall_clock64() - t0 > 50000000ull) {
+        if (wall_clock64() - t0 > sm.wait_ticks) {
             atomicOr(sm.err, 2);
             return qnan();
         }
@@ -1223,7 +1249,7 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2)) : -1;
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);
     double* sq = sc + kNCoef + 2;
     const int tid = threadIdx.x;
@@ -1302,7 +1328,7 @@ __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsi
     }
     atomicOr(sm.err, 2);
 }
-// The number with tag `tag` from this rank's board, once it is there (bounded wait: 0.5 s, then the launch is aborted
+// The number with tag `tag` from this rank's board, once it is there (bounded wait: DevSampler::wait_ticks, then the launch is aborted
 // and the run ends with an error; NaN after an abort).
 __device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col) {
     const unsigned long long* p = board_entry(sm.board, sm, tag, wid, col);
@@ -1314,7 +1340,7 @@ __device__ inline double board_take(const DevSampler& sm, unsigned int tag, int 
             return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
         if ((spin & 15) == 15) {
             if (board_aborted(sm)) return qnan();
-            if (wall_clock64() - t0 > 50000000ull) {
+            if (wall_clock64() - t0 > sm.wait_ticks) {
                 board_abort(sm, 1u, tag, (unsigned int)wid, (unsigned int)col);
                 return qnan();
             }
@@ -1489,8 +1515,11 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // interpolants proved from their first interval, no fitted sigma -- so that the other models' arithmetic is not in its
 // instruction stream (a launch streams its code from L2 into cold instruction caches: 89 KiB of kernel, ~28 KiB of
 // them executed, cost the generic kernel a third of its time).
+// NPARTS = 8: three or four parts again, but FOUR groups of 256 threads, one part each at the same time (1024 threads):
+// for launches of at most one workgroup per CU -- a rank's share of a strongly scaled ensemble, configs[2] on 8 GPUs:
+// 256 proposals -- where a second workgroup to overlap with does not exist and the parts of one proposal can.
 template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false, int MODEL = 0>
-__global__ __launch_bounds__(kBlock * 2, LCF_WAVES)
+__global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
 void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
             const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1503,12 +1532,13 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2)) : -1;
     double* sc = reinterpret_cast<double*>(ltab + pb.stage_d2);  // coefficients, then log-prior
     double* sq = sc + kNCoef + 2;                                           // the proposal
     double* sx = sq + kMaxDim + (kMaxDim & 1);                              // the walker's current position, lp, draw
     int* sctl = reinterpret_cast<int*>(sc + kSoloScratch + 2);              // BOARD: [0] = 1: the launch is aborted
-    constexpr int kThreads = kBlock * 2;
+    constexpr int kGroups = NPARTS == 8 ? 4 : 2;     // groups of 256 threads, each walks one part at a time
+    constexpr int kThreads = kBlock * kGroups;
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const int tid = threadIdx.x, i = blockIdx.x + (BOARD ? slot_lo : 0);
@@ -1564,7 +1594,7 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
                                (unsigned int)(G - 1)) >= 0;
                 abort = board_aborted(sm);
                 if (__all(ok) || abort) break;
-                if (wall_clock64() - t0 > 50000000ull) {
+                if (wall_clock64() - t0 > sm.wait_ticks) {
                     board_abort(sm, 2u, (unsigned int)G, (unsigned int)__builtin_ctzll(~__ballot(ok)), 0u);
                     abort = true;
                     break;
@@ -1615,7 +1645,7 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
         LCF_STAMP(0, 7);
         if (NPARTS > 2) {
 #pragma unroll 1
-            for (int pp = part; pp < pb.n_parts; pp += 2) {
+            for (int pp = part; pp < pb.n_parts; pp += kGroups) {
                 term = epochs_loop<VARIANT, true, kFetch, MODEL, true>(pb, pp, sq, cs, ltab, fdesc, ExpTab{exptab}, ltid, itab_at,
                                                                        first_col, pp == part, pbp, sc);
                 const double ws = wave_sum(term);
@@ -1789,7 +1819,7 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
-                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + 3 * pb.n_filters) * sizeof(double2)) : -1;
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2)) : -1;
     double* scratch = reinterpret_cast<double*>(ltab + pb.stage_d2);       // [GROUP][kPopScratch]
     double* red = scratch + GROUP * kPopScratch;                             // [GROUP][4 * kPopMaxParts] wave sums
     constexpr int kD = ND > 0 ? ND : kMaxDim;
@@ -1905,6 +1935,7 @@ struct lcf_engine {
     int* d_ctab_off = nullptr;  // per filter: (offset, count) of the compressed table
     double* d_ctmin = nullptr;
     bool have_ctab = false, have_itab = false;
+    int n_cus = 256;             // compute units of the device (launch shapes depend on it)
     DevProblem* d_dp = nullptr;  // `dp` in device memory, for the kernels that read it through a pointer
     lcf_status sync_dp() {       // after every change of `dp`
         if (!d_dp) {
@@ -2097,6 +2128,10 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
 
     auto* e = new lcf_engine();
     e->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus;
+    }
     lcf_status st = LCF_OK;
     auto bail = [&](lcf_status s) {
         delete e;
@@ -2317,7 +2352,9 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
                               : INFINITY,
                           have_itab ? f * pr->itab_m * 8 : 0,
                           pcomp[2 * f + 1] > 0 ? 1. / ptmin[f] : 0.,  // t_min = 0 -> inf: always valid
-                          phot[2 * f + 1] > 0 ? 1. / ptmin2[f] : 0.};
+                          phot[2 * f + 1] > 0 ? 1. / ptmin2[f] : 0.,
+                          companion ? pr->filt_kasen_par[f] : -1, companion ? pr->filt_sifto_par[f] : -1,
+                          companion ? pr->filt_dt_par[f] : -1, 0};
     std::vector<double> hexp(kExpTabSize);
     for (int j = 0; j < kExpTabSize; ++j) hexp[j] = std::exp2(j / (double)kExpTabSize);
 
@@ -2385,7 +2422,20 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.itab_uniform = have_itab ? 1 : 0;
     for (int f = 0; have_itab && f < NF; ++f)
         if (!(pr->itab_tmin[f] <= std::exp(pr->itab_u0) * (1. + 1e-12))) dp.itab_uniform = 0;
-    dp.stage_d2 = dp.n_lds_tab + 3 * NF + dp.n_itab_lds / 2;
+    // ... and a companion-shocking model's template splines behind those, when their knots are exactly k0 + i h (the
+    // device then needs no knot) and everything still leaves room for two workgroups per CU (80 KiB each): 26 KiB for
+    // the eight SiFTO filters -- a point's template costs two LDS reads instead of a chain of dependent loads from L2
+    dp.n_spl_lds = 0;
+    if (companion && dp.tab_in_lds) {
+        const double h1 = pr->spline_knots[1] - pr->spline_knots[0];
+        bool exact = h1 > 0.;
+        for (int k = 0; exact && k < pr->n_knots; ++k) exact = pr->spline_knots[k] == pr->spline_knots[0] + k * h1;
+        const size_t n_spl = (size_t)NF * (pr->n_knots - 1) * 4;
+        const size_t before = kLdsHead * sizeof(double) + ((size_t)dp.n_lds_tab + kFdD2 * NF) * sizeof(double2) +
+                              (size_t)dp.n_itab_lds * sizeof(double);
+        if (exact && before + n_spl * sizeof(double) + 2048 <= 80 * 1024) dp.n_spl_lds = (int)n_spl;
+    }
+    dp.stage_d2 = dp.n_lds_tab + kFdD2 * NF + dp.n_itab_lds / 2 + dp.n_spl_lds / 2;
     std::memcpy(dp.consts, pr->consts, sizeof(dp.consts));
     if (pr->model == LCF_MODEL_SHOCK_COOLING || pr->model == LCF_MODEL_SHOCK_COOLING3)
         dp.consts[11] = pr->consts[1] > 0. ? std::log(pr->consts[1] / 19.5) : 0.;  // hoisted out of the half-step
@@ -2399,7 +2449,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     e->lds_bytes = kLdsHead * sizeof(double) + (dp.tab_in_lds ? (size_t)dp.stage_d2 * sizeof(double2) : 0);
 
     double *dt, *dy_, *ddy, *dkn = nullptr, *dspl = nullptr;
-    int *dfilt, *dorig, *dk = nullptr, *ds = nullptr, *ddt = nullptr;
+    int *dfilt, *dorig;
     double2* dtab;
     PriorDev* dpri = nullptr;
 #define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
@@ -2428,11 +2478,12 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         if (dp.tab_in_lds) {
             himg.insert(himg.end(), htab.begin(), htab.begin() + dp.n_lds_tab);
             const double2* fd2 = reinterpret_cast<const double2*>(hfd.data());
-            himg.insert(himg.end(), fd2, fd2 + 3 * NF);
+            himg.insert(himg.end(), fd2, fd2 + kFdD2 * NF);
             for (int k = 0; k < dp.n_itab_lds; k += 2) {
                 const double a = pr->itab_coef[k], b = pr->itab_coef[k + 1];
                 himg.push_back(make_double2(std::isfinite(a) ? a : 0., std::isfinite(b) ? b : 0.));
             }
+            for (int k = 0; k < dp.n_spl_lds; k += 2) himg.push_back(make_double2(pr->spline_coef[k], pr->spline_coef[k + 1]));
         }
         double2* dimg;
         UP(himg, dimg);
@@ -2483,8 +2534,6 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.epoch_t = depocht;
     dp.exp2tab = dexp;
     if (companion) {
-        std::vector<int> hk(pr->filt_kasen_par, pr->filt_kasen_par + NF), hs(pr->filt_sifto_par, pr->filt_sifto_par + NF),
-            hd(pr->filt_dt_par, pr->filt_dt_par + NF);
         std::vector<double> hkn(pr->spline_knots, pr->spline_knots + pr->n_knots),
             hsp(pr->spline_coef, pr->spline_coef + (size_t)NF * (pr->n_knots - 1) * 4);
         for (int k = 1; k < pr->n_knots; ++k)
@@ -2494,7 +2543,15 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
         for (int k = 0; k < pr->n_knots; ++k)
             uniform = uniform && std::fabs(hkn[k] - (hkn.front() + k * h)) <= 1e-9 * h;
         dp.knot_inv_h = uniform ? 1. / h : 0.;
-        UP(hk, dk); UP(hs, ds); UP(hd, ddt); UP(hkn, dkn); UP(hsp, dspl);
+        // knots that ARE k0 + i h in float64 (SiFTO: integer days): interval by arithmetic, no knot read on the device
+        const double h1 = hkn[1] - hkn[0];
+        bool exact = pr->n_knots >= 2 && h1 > 0.;
+        for (int k = 0; exact && k < pr->n_knots; ++k) exact = hkn[k] == hkn[0] + k * h1;
+        dp.knot0 = hkn.front();
+        dp.knot_last = hkn.back();
+        dp.knot_h = exact ? h1 : 0.;
+        if (exact) dp.knot_inv_h = 1. / h1;
+        UP(hkn, dkn); UP(hsp, dspl);
     }
     if (pr->priors) {
         std::vector<PriorDev> hp(n_dim);
@@ -2507,7 +2564,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     }
 #undef UP
     dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_filt = dfilt; dp.pt_orig = dorig;
-    dp.tab = dtab; dp.f_kpar = dk; dp.f_spar = ds; dp.f_dtpar = ddt;
+    dp.tab = dtab;
     dp.knots = dkn; dp.spl = dspl; dp.priors = dpri;
     if ((st = e->sync_dp()) != LCF_OK) return bail(st);
     *out = e;
@@ -2904,7 +2961,7 @@ bool fused_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_FUSED") != nullptr;
     const lcf_engine* e = s->e;
     return !disabled && s->half_step_kernel != LCF_HALF_STEP_PHASES && e->dp.tab_in_lds &&
-           fused_lds_bytes(e) <= 64 * 1024;  // (measured with 160 KiB allowed: see DESIGN.md section 5 -- no gain)
+           fused_lds_bytes(e) <= 80 * 1024;  // (two workgroups per CU; measured with 160 KiB allowed: no gain)
 }
 
 // One launch for a whole half-step of a single-GPU run: commit half-step g_next - 1 (if pending), draw half-step
@@ -2999,13 +3056,13 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
         if (lds > 64 * 1024) /* allow more than the default 64 KiB of dynamic LDS (per function and device) */       \
             LCF_HIP(hipFuncSetAttribute((const void*)k_solo<ND, V, T, NP, B, M>,                                      \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));                 \
-        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, ds, row, draws,    \
-                           draws_next, G, g_run0, lo);                                                                \
+        hipLaunchKernelGGL((k_solo<ND, V, T, NP, B, M>), grid, dim3(kBlock * (NP == 8 ? 4 : 2)), lds, st, e->d_dp, ds, row, \
+                           draws, draws_next, G, g_run0, lo);                                                         \
     } while (0)
 #define LCF_SOLO5(ND, V, T, NP, B)                                                                                    \
     do {                                                                                                              \
-        if (ND == 5 && spec == kShockCooling) LCF_SOLO6(5, V, T, NP, B, kShockCooling);                               \
-        else if (ND == 4 && spec == kShockCooling2) LCF_SOLO6(4, V, T, NP, B, kShockCooling2);                        \
+        if (NP != 8 && ND == 5 && spec == kShockCooling) LCF_SOLO6(5, V, T, (NP == 8 ? 4 : NP), B, kShockCooling);    \
+        else if (NP != 8 && ND == 4 && spec == kShockCooling2) LCF_SOLO6(4, V, T, (NP == 8 ? 4 : NP), B, kShockCooling2); \
         else LCF_SOLO6(ND, V, T, NP, B, 0);                                                                           \
     } while (0)
 #define LCF_SOLO4(ND, V, T, NP)                                                                                       \
@@ -3013,9 +3070,12 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
         if (board) LCF_SOLO5(ND, V, T, NP, true); else LCF_SOLO5(ND, V, T, NP, false);                                \
     } while (0)
     // workgroups of 512 threads: one part per 256 threads (up to two parts) or two (three or four)
+    // ... or four (1024 threads) where the launch has at most one workgroup per CU
+    static const bool no_wide = std::getenv("LCF_NO_WIDE_SOLO") != nullptr;
+    const bool wide = !no_wide && e->dp.n_parts > 2 && (int)grid.x <= e->n_cus;
 #define LCF_SOLO3(ND, V, T)                                                                                           \
     do {                                                                                                              \
-        if (e->dp.n_parts <= 2) LCF_SOLO4(ND, V, T, 2); else LCF_SOLO4(ND, V, T, 4);                                  \
+        if (e->dp.n_parts <= 2) LCF_SOLO4(ND, V, T, 2); else if (wide) LCF_SOLO4(ND, V, T, 8); else LCF_SOLO4(ND, V, T, 4); \
     } while (0)
 #define LCF_SOLO(ND) LCF_SOLO3(ND, 1, true)
     switch (ds.n_dim) {
@@ -3242,6 +3302,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     ds.key0 = (uint32_t)(seed & 0xffffffffu);
     ds.key1 = (uint32_t)(seed >> 32);
     ds.a = a;
+    ds.wait_ticks = peer_wait_ticks();
     const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
     lcf_status st;
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
@@ -3382,6 +3443,9 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     int err = 0;
     std::memcpy(&err, s->snap, sizeof(int));
     if (err & 2) {
+        // (an aborted multi-rank run leaves the ranks with different states -- a rank has committed its own walkers of
+        // the half-step the others gave up on: the ensemble must be set again, on every rank, before the next run)
+        const double sec = (double)s->ds.wait_ticks / 1e8;
         unsigned int w[5] = {0, 0, 0, 0, 0};
         if (s->board_mem)
             hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - 5 * sizeof(unsigned int), sizeof w,
@@ -3390,13 +3454,17 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
             char msg[200];
             if (w[1] == 1)
                 std::snprintf(msg, sizeof msg, "row-board run: version %u of walker %u (column %u) was not posted within "
-                              "0.5 s: a rank is missing or behind", w[2], w[3], w[4]);
+                              "%.1f s: a rank is missing or behind (set_state is required on all ranks before the next run)",
+                              w[2], w[3], w[4], sec);
             else
-                std::snprintf(msg, sizeof msg, "row-board run: half-step %u waited 0.5 s for rank %u to finish half-step "
-                              "%u", w[2], w[3], w[2] - 2);
+                std::snprintf(msg, sizeof msg, "row-board run: half-step %u waited %.1f s for rank %u to finish half-step "
+                              "%u (set_state is required on all ranks before the next run)", w[2], sec, w[3], w[2] - 2);
             return fail(LCF_ERR_STATE, msg);
         }
-        return fail(LCF_ERR_STATE, "a peer's rows did not arrive within 0.5 s (peer-mailbox run)");
+        char msg[200];
+        std::snprintf(msg, sizeof msg, "a peer's rows did not arrive within %.1f s (peer-mailbox run; set_state is required "
+                      "on all ranks before the next run)", sec);
+        return fail(LCF_ERR_STATE, msg);
     }
     if (err) return fail(LCF_ERR_NAN_LOGPROB, "Probability function returned NaN");
     return LCF_OK;

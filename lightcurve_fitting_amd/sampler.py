@@ -241,6 +241,70 @@ class PopulationSampler:
         return self.samplers[k]
 
 
+#: multi-rank drivers in the order they are probed (fastest expected first)
+COLLECTIVES = ('rows', 'peers', 'allgather')
+_probe_cache = {}   # (process group, world size) -> the driver the first probe in that group selected
+
+
+def probe_collectives(make_sampler, dist, x0, probe_steps=20, group=None, modes=COLLECTIVES):
+    """Which multi-rank driver runs an ensemble fastest on THIS node: every driver in ``modes`` gets a few untimed steps
+    from ``x0`` on a sampler of its own (``make_sampler(mode)``); one that raises on any rank (its waits are bounded),
+    that could not connect its peer memory, or that leaves the ranks with different replicas of the ensemble is out; of
+    the rest the fastest (the slowest rank's time counts) wins.  Returns ``(sampler, report)``.
+
+    Every rank takes the same path: success is AGREED (all-reduce of a flag) after the sampler is made, after its first
+    short run and after the probe run, and a stage is skipped on every rank as soon as one rank failed the one before
+    -- a rank that raised never sits in a different collective than the ranks that did not."""
+    import time
+    import torch
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+
+    def agreed(ok):   # logical AND over the ranks
+        flag = torch.tensor([1. if ok else 0.], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return float(flag[0]) == 1.
+
+    weights = np.cos(np.arange(x0.size, dtype=np.float64)).reshape(x0.shape)
+    report, best = {}, None
+    for mode in modes:
+        seconds, checksum, why, s = float('inf'), 0., None, None
+        try:
+            s = make_sampler(mode)
+        except Exception as exc:  # noqa: BLE001
+            why = f'{type(exc).__name__}: {exc}'[:200]
+        ok = agreed(why is None)
+        if ok:
+            try:
+                s.run_mcmc(x0, 5, store=False)
+                if (mode == 'peers' and not s._peers) or (mode == 'rows' and not s._boards):
+                    why = 'the peer memory could not be connected'
+            except Exception as exc:  # noqa: BLE001
+                why = f'{type(exc).__name__}: {exc}'[:200]
+            ok = agreed(why is None)
+        if ok:
+            try:
+                t0 = time.perf_counter()
+                state = s.run_mcmc(None, probe_steps, store=False)   # (returns after the device has finished)
+                seconds = time.perf_counter() - t0
+                checksum = float(np.sum(np.asarray(state[0]) * weights))
+            except Exception as exc:  # noqa: BLE001
+                seconds, why = float('inf'), f'{type(exc).__name__}: {exc}'[:200]
+            ok = agreed(why is None)
+        agg = torch.tensor([seconds if np.isfinite(seconds) else 1e30, checksum, -checksum], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.MAX, group=group)
+        worst, hi, lo = float(agg[0]), float(agg[1]), -float(agg[2])
+        ok = ok and worst < 1e29 and hi == lo
+        report[mode] = {'ok': ok, 'ms_per_step': 1e3 * worst / probe_steps if worst < 1e29 else None,
+                        'replicas_agree': hi == lo, 'note': why}
+        if ok and (best is None or worst < best[0]):
+            best = (worst, mode, s)
+    if best is None:
+        raise RuntimeError(f'no multi-GPU driver completed its probe: {report}')
+    report['selected'] = best[1]
+    report['probe_steps'] = probe_steps
+    return best[2], report
+
+
 class EnsembleSampler:
     """Drop-in for the subset of ``emcee.EnsembleSampler`` the reference uses, bound to one engine.
 
@@ -273,13 +337,16 @@ class EnsembleSampler:
         self._group = group
         self._force_sharded = force_sharded  # run the phase-by-phase collective path even with a single rank
         self.native_collectives = native_collectives
-        #: how the ranks of a multi-GPU run exchange the rows of a half-step: 'allgather' (default: one RCCL all-gather
-        #: per half-step) or 'peers' (direct stores into every rank's mailbox over IPC-mapped memory, no collective;
-        #: behind this switch / LCF_COLLECTIVE=peers until it has been measured on a multi-GPU node)
+        #: how the ranks of a multi-GPU run work together: 'rows' (every rank moves its share of the walkers with k_solo
+        #: and stores their new rows into every rank's board over IPC-mapped memory), 'peers' (every rank evaluates its
+        #: share, stores partial sums into every mailbox, replicates the bookkeeping), 'allgather' (the same with one RCCL
+        #: all-gather per half-step), or 'auto' (default; LCF_COLLECTIVE overrides): the first run of the first sampler
+        #: of a process group probes all three for a few steps (probe_collectives) and the group keeps the fastest
         import os
-        self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'allgather')
-        if self.collective not in ('allgather', 'peers', 'rows'):
-            raise ValueError("collective must be 'allgather', 'peers' or 'rows'")
+        self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'auto')
+        if self.collective not in COLLECTIVES + ('auto',):
+            raise ValueError("collective must be 'auto', 'allgather', 'peers' or 'rows'")
+        self.collective_probe = None   # the report of the probe this sampler ran (None: named, cached or single rank)
         self._boards = None
         self._peers = None  # True once the mailboxes are connected, False if unavailable
         self._comm = None  # NativeComm once created, False if unavailable
@@ -390,6 +457,25 @@ class EnsembleSampler:
             self._boards = ok
         return self._boards
 
+    def _resolve_collective(self):
+        """'auto' -> the driver this process group runs fastest: probed once per group (on samplers of their own, a few
+        steps from this sampler's present state), then remembered.  Every rank gets here at the same run."""
+        import torch.distributed as dist
+        key = (id(self._group), dist.get_world_size(self._group))
+        if key not in _probe_cache:
+            x0 = self._native.get_state()[0]
+            made = []
+
+            def make(mode):
+                made.append(EnsembleSampler(self.nwalkers, self.ndim, self.engine, seed=self.seed + 7919,
+                                            randomize_split=self.randomize_split, group=self._group, collective=mode,
+                                            native_collectives=self.native_collectives))
+                return made[-1]
+            _, self.collective_probe = probe_collectives(make, dist, x0, group=self._group)
+            _probe_cache[key] = self.collective_probe['selected']
+            made.clear()
+        self.collective = _probe_cache[key]
+
     def _distributed(self):
         try:
             import torch.distributed as dist
@@ -462,6 +548,8 @@ class EnsembleSampler:
         if self.randomize_split and self.nwalkers > 16384:  # beyond the device sort: host-generated colouring
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         self._in_flight = False
+        if self.collective == 'auto' and self._distributed():
+            self._resolve_collective()
         try:
             if self._distributed() and self.collective == 'rows' and self._peer_boards():
                 import torch.distributed as dist

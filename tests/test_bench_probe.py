@@ -16,18 +16,27 @@ import bench  # noqa: E402
 
 class FakeDist:
     """One process standing in for the group: a reduction returns what this rank contributed -- or, for the rank that
-    disagrees, a different replica checksum."""
+    disagrees, a different replica checksum; `other_rank_fails_at` = the agreement point (0: sampler made, 1: first run,
+    2: probe run) at which ANOTHER rank reports a failure."""
     class ReduceOp:
         MAX = 'max'
+        MIN = 'min'
 
-    def __init__(self, other_rank_checksum_offset=0.):
+    def __init__(self, other_rank_checksum_offset=0., other_rank_fails_at=None):
         self.offset = other_rank_checksum_offset
+        self.fails_at = other_rank_fails_at
+        self.agreements = 0
 
     @staticmethod
-    def get_backend():
+    def get_backend(group=None):
         return 'gloo'
 
-    def all_reduce(self, t, op=None):
+    def all_reduce(self, t, op=None, group=None):
+        if op == 'min':        # an agreement point
+            if self.fails_at is not None and self.agreements % 3 == self.fails_at:
+                t[0] = 0.
+            self.agreements += 1 if float(t[0]) == 1. else 3 - self.agreements % 3   # (a failed stage skips the later ones)
+            return
         if self.offset:        # another rank holds a different state: max(c, c') and max(-c, -c') no longer mirror
             t[1] = max(float(t[1]), float(t[1]) + self.offset)
 
@@ -75,6 +84,19 @@ def test_ranks_with_different_replicas_disqualify_a_driver():
     with pytest.raises(RuntimeError, match='no multi-GPU driver completed'):
         bench.pick_collective(lambda mode: FakeSampler(mode, 0.001), FakeDist(other_rank_checksum_offset=1.), np.ones((4, 2)),
                               _args())
+
+
+def test_a_failure_on_another_rank_skips_the_later_stages_here_too():
+    """The ranks agree on success after every stage: when another rank could not finish its first run, THIS rank does not
+    start the probe run of that driver either (it would sit in the run's collectives alone)."""
+    made = {}
+
+    def make(mode):
+        made[mode] = FakeSampler(mode, 0.001)
+        return made[mode]
+    with pytest.raises(RuntimeError, match='no multi-GPU driver completed'):
+        bench.pick_collective(make, FakeDist(other_rank_fails_at=1), np.ones((4, 2)), _args())
+    assert all(s.calls == 1 for s in made.values())      # the 5-step run only, never the probe run
 
 
 def test_a_named_driver_is_not_probed():

@@ -273,6 +273,26 @@ def test_peer_mailboxes_between_processes(ranks):
     assert line['every_rank_equals_the_single_gpu_chain'] and line['peer_mailboxes_connected_on_every_rank']
 
 
+def test_collective_none_probes_and_picks_a_driver_between_processes():
+    """EnsembleSampler(collective=None) with two real processes: the first run probes rows / peers / all-gather (the ranks
+    agree on the fastest one that works), the chain is the single-GPU chain whichever won, and a second sampler of the
+    same process group reuses the choice without probing again."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LCF_COLLECTIVE')}
+    env['LCF_PEER_WAIT_S'] = '0.5'     # (two ranks that share a device may starve each other in the row-board probe)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'peer_ranks_check.py'), '2', '48', '10', 'auto'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['requested'] == 'auto' and line['driver'] == line['probe']['selected']
+    assert line['every_rank_equals_the_single_gpu_chain'] and line['connected_on_every_rank']
+    assert line['probe'][line['driver']]['ok'] and line['probe']['peers']['replicas_agree']
+
+
 @pytest.mark.parametrize('nwalkers', [21, 64])
 def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
     """Population mode with shared epochs runs ONE launch per half-step for all transients (k_pop: a workgroup per four
@@ -344,11 +364,13 @@ def test_row_boards_companion_shape():
         assert np.array_equal(s.naccepted(), ref.naccepted())
 
 
-def test_row_boards_missing_rank_ends_with_an_error():
-    """A rank that never runs: the waits of the other one are bounded (0.5 s), the run ends with LCF_ERR_STATE and says
-    which row was missing -- it does not hang the device."""
+def test_row_boards_missing_rank_ends_with_an_error(monkeypatch):
+    """A rank that never runs: the waits of the other one are bounded (LCF_PEER_WAIT_S, here 0.5 s; 5 s by default), the
+    run ends with LCF_ERR_STATE, says which row was missing and that the ensemble must be set again -- it does not hang
+    the device."""
     import time
     from lightcurve_fitting_amd.engine import LcfError
+    monkeypatch.setenv('LCF_PEER_WAIT_S', '0.5')       # (read when a sampler is created)
     pb, eng = _multiband()
     nwalkers = 48
     x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(4).standard_normal((nwalkers, 5)))
@@ -364,7 +386,7 @@ def test_row_boards_missing_rank_ends_with_an_error():
     with pytest.raises(LcfError) as err:
         samplers[0].run_rows(0, 6, 'random', True)     # rank 1 never starts
     assert time.perf_counter() - t0 < 5.
-    assert err.value.status == 7 and 'was not posted within 0.5 s' in str(err.value)
+    assert err.value.status == 7 and 'was not posted within 0.5 s' in str(err.value) and 'set_state is required' in str(err.value)
     # the sampler is usable again after a new set_state
     samplers[0].set_state(x0)
     samplers[0].run(0, 3, 'random', True)

@@ -4,9 +4,11 @@ mailboxes through HIP IPC, stores its shard's rows straight into them and polls 
 with no collective (what xGMI peer writes do on a node; here the peers' memory is the same device).  Every rank must
 end with the chain of the single-GPU run, bit for bit.
 
-    python tools/peer_ranks_check.py [n_ranks=2] [n_walkers=64] [n_steps=12] [peers|rows]
+    python tools/peer_ranks_check.py [n_ranks=2] [n_walkers=64] [n_steps=12] [peers|rows|auto]
 
 `rows`: the same check for the row boards (every rank moves its share of the walkers itself and posts their rows).
+`auto`: EnsembleSampler(collective=None) -- the sampler probes the three drivers on its first run (the ranks agree on the
+fastest one that works) and runs with it; the line says which.
 
 Started without a launcher it spawns the ranks itself (fresh processes; the parent never touches the GPU); rank 0
 prints one JSON line."""
@@ -56,18 +58,27 @@ def main():
     ref = EnsembleSampler(n_walkers, 5, eng, seed=2024, group=None, collective='allgather')
     ref._distributed = lambda: False          # the single-GPU run of the same ensemble
     ref.run_mcmc(x0, n_steps)
-    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective=driver)
+    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective=None if driver == 'auto' else driver)
     s.run_mcmc(x0, n_steps // 2)
+    probe = s.collective_probe
+    if driver == 'auto':
+        assert s.collective in ('rows', 'peers', 'allgather') and probe is not None and probe['selected'] == s.collective
+        driver = s.collective
+        t = EnsembleSampler(n_walkers, 5, eng, seed=1, collective=None)     # a second sampler of the group: no new probe
+        t.run_mcmc(x0, 2)
+        assert t.collective == s.collective and t.collective_probe is None
     s.run_mcmc(None, n_steps - n_steps // 2)   # a second run: generations continue, the barrier between runs
     same = bool(np.array_equal(s.get_chain(), ref.get_chain()) and np.array_equal(s.get_log_prob(), ref.get_log_prob()) and
                 np.array_equal(s.acceptance_fraction, ref.acceptance_fraction) and
                 np.array_equal(s._state[0], ref._state[0]))
     flags = [None] * n_ranks
-    dist.all_gather_object(flags, (same, bool(s._boards if driver == 'rows' else s._peers), float(s.last_run_ms)))
+    connected = s._boards if driver == 'rows' else s._peers if driver == 'peers' else True
+    dist.all_gather_object(flags, (same, bool(connected), float(s.last_run_ms)))
     if rank == 0:
         print(json.dumps({'ranks': n_ranks, 'walkers': n_walkers, 'steps': n_steps,
                           'every_rank_equals_the_single_gpu_chain': all(f[0] for f in flags),
-                          'driver': driver, 'connected_on_every_rank': all(f[1] for f in flags),
+                          'driver': driver, 'requested': sys.argv[4] if len(sys.argv) > 4 else 'peers',
+                          'probe': probe, 'connected_on_every_rank': all(f[1] for f in flags),
                           'peer_mailboxes_connected_on_every_rank': driver == 'peers' and all(f[1] for f in flags),
                           'device_ms_last_run': [f[2] for f in flags],
                           'acceptance': float(s.acceptance_fraction.mean())}), flush=True)
