@@ -64,7 +64,7 @@ def test_fastest_working_driver_is_selected():
     made = {}
 
     def make(mode):
-        made[mode] = FakeSampler(mode, {'rows': 0.02, 'peers': 0.002, 'allgather': 0.05}[mode])
+        made[mode] = FakeSampler(mode, {'rows': 0.08, 'peers': 0.004, 'allgather': 0.2}[mode])
         return made[mode]
     s, report = bench.pick_collective(make, FakeDist(), np.ones((4, 2)), _args())
     assert report['selected'] == 'peers' and s is made['peers']
