@@ -620,7 +620,8 @@ def run_companion(args):
     scaling = args.scaling or 'strong'
     nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
     engine = model.engine_for(lc, priors=priors)
-    engine._variant = 3
+    engine.set_variant(args.variant)
+    engine._variant = args.variant
     x0 = companion_walkers(nw)
     quiet_interpreter()
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(nw, 8, engine, seed=SEED, collective=mode), dist, x0,
@@ -638,9 +639,15 @@ def run_companion(args):
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
         name = {'solo': 'k_solo<8,1,true,4> (one 512-thread workgroup per proposal, its two halves take two of the four parts each)', 'fused': 'k_fused<8,1,true>',
                 'phases': 'k_step + k_points'}[used]
+        # (the committed counters are those of the default configuration -- k_solo, interpolated level, one GPU; anything
+        # else has no PMC pass of its own and reports null; on N > 1 GPUs kernel_ms is the single-GPU k_solo launch of one
+        # rank's share, whichever driver runs the timed steps)
+        pmc_tag = 'k_solo_companion' if (used, args.variant, world) == ('solo', 3, 1) else f'k_{used}_v{args.variant}_companion_x{world}'
         roof = roofline_block(name, kern_ms, per_rank // 2, quads, None, PEAK_FP64_TINSTR, alg_instr,
-                              8 * (8 + 1), 'k_solo_companion', waves_per_launch=(per_rank // 2) * 8,
+                              8 * (8 + 1), pmc_tag, waves_per_launch=(per_rank // 2) * 8,
                               interp=(n_interp, 1000, 'log_lean') if n_interp else None)
+        if world > 1:
+            roof['kernel'] += " [one rank's share as a single-GPU launch: the reference point of the multi-rank drivers]"
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',

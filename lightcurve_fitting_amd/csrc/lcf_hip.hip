@@ -3856,8 +3856,18 @@ lcf_status lcf_sampler_wait(lcf_sampler* s) {
 
 lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                            const int32_t* perm, int32_t store_chain) {
+    static const bool trace = std::getenv("LCF_TRACE_RUN") != nullptr;   // (diagnostic: host time of the two halves)
+    const auto t0 = std::chrono::steady_clock::now();
     if (lcf_status st = lcf_sampler_run_async(s, first_step, n_steps, split_mode, perm, store_chain)) return st;
-    return lcf_sampler_wait(s);
+    const auto t1 = std::chrono::steady_clock::now();
+    const lcf_status r = lcf_sampler_wait(s);
+    if (trace) {
+        const auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "lcf_sampler_run: %lld steps enqueued in %.1f us, waited %.1f us, device %.1f us\n",
+                     (long long)n_steps, std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(t2 - t1).count(), 1e3 * s->last_ms);
+    }
+    return r;
 }
 
 // Population mode: the same n_steps for `n` samplers (one transient each, same walker count) with ONE k_step and ONE
