@@ -112,7 +112,7 @@ struct DevProblem {
     const double2* pt_yd;  // (y, 1/dy) per point -- (y, dy) when sigma is fitted -- for one 16-byte load
     const double* epoch_t; // [n_epochs]
     const double* exp2tab;   // 2^(j/256), j = 0..255
-    const double2* stage_image;  // [exp table | 16 doubles | first n_lds_tab samples of tab | f_desc | staged itab]
+    const double2* stage_image;  // [exp table | 32 doubles | first n_lds_tab samples of tab | f_desc | staged itab | splines]
     int stage_n16, pad5;         // its length in 16-byte units (the exp table and its pad only when !tab_in_lds)
     const double2* tab;  // (a_k, W_k)
     const double* tab_ext;  // ShockCooling3: 0.4 log2(10) A_k / E(B-V) per table sample (0 for padding), else null
@@ -169,10 +169,10 @@ struct ExpTab {
 };
 
 constexpr int kExpTabSize = 256;
-// Head of every kernel's dynamic LDS: the exp table, then 16 doubles for the wave sums of a reduction; the staged
+// Head of every kernel's dynamic LDS: the exp table, then 32 doubles for the wave sums of a reduction; the staged
 // region (band tables, filter descriptors, interpolants) follows.  DevProblem::stage_image is a copy of all of it in
 // global memory, in this layout, so that staging is ONE flat copy with all its loads in flight together.
-constexpr int kLdsHead = kExpTabSize + 16;   // doubles
+constexpr int kLdsHead = kExpTabSize + 32;   // doubles (4 wave sums for each of up to kMaxParts parts)
 constexpr double kInvLn2N = 369.3299304675746;  // 256 / ln 2
 constexpr double kQ1 = 0.0027076061740622863, kQ2 = 3.665565596910106e-06, kQ3 = 3.308302680541371e-09, kQ4 = 2.239395190875157e-12;
 

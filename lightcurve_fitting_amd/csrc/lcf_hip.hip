@@ -135,16 +135,18 @@ __device__ __forceinline__ double band_sum_at(const TabSel<TabPtr>& ts, bool use
 // `lds_at` >= 0: the interpolants are staged in LDS at that byte offset of the workgroup's dynamic LDS (the address is
 // formed from the LDS symbol itself, so that the reads are ds_read_b128 and not generic-pointer loads); < 0: global.
 // r = the temperature's interval coordinate (thermal_state_log): interval (int)r, position 2 frac(r) - 1 in [-1, 1).
-__device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int lds_at, int ioff, double r) {
+// (Measured and not kept: a row of padding behind every filter's rows in the staged copy, against bank conflicts between
+// lanes that hold different filters -- no change for photometry without shared epochs, 26.1 against 25.7 us.)
+__device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int lds_at, int filt, double r) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int j = (int)r;
     const double s = fma(__builtin_amdgcn_fract(r), 2., -1.);
     double2 q0, q1, q2, q3;
     if (lds_at >= 0) {
-        const double2* q = reinterpret_cast<const double2*>(smem + lds_at) + (ioff + 8 * j) / 2;
+        const double2* q = reinterpret_cast<const double2*>(smem + lds_at) + (filt * pb.itab_m * 8 + 8 * j) / 2;
         q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     } else {
-        const double2* q = reinterpret_cast<const double2*>(pb.itab + ioff + 8 * j);
+        const double2* q = reinterpret_cast<const double2*>(pb.itab + filt * pb.itab_m * 8 + 8 * j);
         q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     }
     double g = fma(q0.x, s, q0.y);
@@ -174,13 +176,11 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     // wave is inside its filter's proved range -- a per-wave choice, like the fast / safe band sums, so that a walker's
     // result never depends on how walkers are batched -- else the sample tables after one exponential each.
     bool by_table = false;
-    int ioff = filt * pb.itab_m * 8;
     if (ITAB && VARIANT != 0 && (MODEL || pb.use_itab)) {
         const bool log_form = __double2hiint(invT) >= 0;   // (-0.0 and -1/T have the sign bit set)
         bool inside = log_form;
         if ((!MODEL && !pb.itab_uniform) || model == kShockCooling4) {
             const long long fmeta = __double_as_longlong(fd[1].y);   // {float r_min, int ioff} of the filter's interpolant
-            ioff = (int)(fmeta >> 32);
             // (ShockCooling4 also needs the band sum at 0.74 T: ln 0.74 / h intervals lower)
             const double r_low = model == kShockCooling4 ? invT - 0.3011050927839216 * pb.itab_inv_h : invT;
             inside = log_form && r_low >= (double)__int_as_float((int)fmeta);
@@ -195,9 +195,9 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
         }
     }
     if (by_table) {
-        double L = interp_log_band_sum(pb, itab_at, ioff, invT);
+        double L = interp_log_band_sum(pb, itab_at, filt, invT);
         if (model == kShockCooling4)  // min(blackbody, suppressed blackbody at 0.74 T), models.py:629-631
-            L = fmin(L, interp_log_band_sum(pb, itab_at, ioff, invT - 0.3011050927839216 * pb.itab_inv_h) + 1.2044203711356864);
+            L = fmin(L, interp_log_band_sum(pb, itab_at, filt, invT - 0.3011050927839216 * pb.itab_inv_h) + 1.2044203711356864);
         // (|ln R_bb^2| <= 600 and |ln S| < 100: the exponent can be added as an integer)
         yfit = exp_scaled<false>(fma(L, kInvLn2N, pref * kInvLn2N), et);
     } else if (!STAGED && invT > 0. && pb.redden_slow) {
@@ -518,13 +518,30 @@ __device__ inline double epochs_loop(const DevProblem& pb, int part, const doubl
     const int lane = vtid & 63, v64 = __builtin_amdgcn_readfirstlane(vtid & ~63);
     const bool by_itab = MODEL ? true : VARIANT != 0 && pb.use_itab;
     const bool fast_kind = columns_fast_kind<MODEL>(pb, by_itab);
+    // (generic kernels only: compiled into the model-specialised ones as well it cost them their registers -- 2 to 34
+    // spilled -- and photometry without shared epochs ran no faster there, 25.7 against 26.0 us)
+    const bool ragged_fast = !MODEL && by_itab && !pb.em_dense && pb.itab_uniform && !pb.use_sigma &&
+                             (pb.model == kShockCooling || pb.model == kShockCooling2);
     double term = 0.;
+    // (a lane's columns are 256 apart: the time of the next one is requested while this one is computed -- in the generic
+    // kernels; the model-specialised ones have no registers to spare for it)
+    constexpr bool kAhead = MODEL == 0;
+    double t_next = 0.;
+    if (kAhead && c0 + v64 < c1 && !(FETCHED && use_first)) t_next = pb.em_t[min(c0 + v64 + lane, c1 - 1)];
 #pragma unroll 1
     for (int cb = c0 + v64; cb < c1; cb += kBlock) {
         const bool live = cb + lane < c1;
         const int col = live ? cb + lane : c1 - 1;   // lanes beyond the part repeat its last column; their terms are dropped
         const bool fetched = FETCHED && use_first && cb < c0 + kBlock;
-        const double t_in = fetched ? first.t : pb.em_t[col];
+        const double t_in = fetched ? first.t : kAhead ? t_next : pb.em_t[col];
+        if (kAhead && cb + kBlock < c1) t_next = pb.em_t[min(cb + kBlock + lane, c1 - 1)];
+        // ragged columns: the first point's filter and photometry too, ahead of the state's arithmetic
+        int filt0 = 0;
+        double2 o0 = make_double2(0., 0.);
+        if (ragged_fast) {
+            filt0 = pb.em_filt[col];
+            o0 = pb.em_yd[col];
+        }
         double x, pr;   // the log-space pair of thermal_state_log, or (1/T, R_bb^2)
         if (by_itab) {
             thermal_state_log<MODEL>(pb, c, t_in, x, pr, et);
@@ -533,6 +550,27 @@ __device__ inline double epochs_loop(const DevProblem& pb, int part, const doubl
             thermal_state<MODEL>(pb, c, t_in, T, x, pr);
         }
         LCF_STAMP(0, 13);
+        if (ragged_fast && __builtin_amdgcn_ballot_w64(__double2hiint(x) < 0) == 0) {
+            // columns that are NOT one point of every filter (photometry whose observations have their own times: one
+            // point per column): the same interpolated arithmetic with the filter read per lane
+            const double lnr2k = pr * kInvLn2N;
+            const int nc = pb.em_cols;
+            double acc = 0.;
+#pragma unroll 1
+            for (int k = 0; k < pb.em_k; ++k) {
+                int filt = filt0;
+                double2 o = o0;
+                if (k > 0) {   // (not a select between a register and a load: that puts the register in scratch memory)
+                    filt = pb.em_filt[(size_t)k * nc + col];
+                    o = pb.em_yd[(size_t)k * nc + col];
+                }
+                const double L = interp_log_band_sum(pb, itab_at, max(filt, 0), x);
+                const double q = (o.x - exp_scaled<false>(fma(L, kInvLn2N, lnr2k), et)) * o.y;
+                acc = filt >= 0 ? fma(q, q, acc) : acc;
+            }
+            term += live ? acc : 0.;
+            continue;
+        }
         if (fast_kind && __builtin_amdgcn_ballot_w64(__double2hiint(x) < 0) == 0) {
             const int row = 8 * (int)x;
             const double s = fma(__builtin_amdgcn_fract(x), 2., -1.);
@@ -804,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_bb_pointwise(const DevProblem pb, in
         if (VARIANT != 0 && pb.use_itab) {
             const double x = (log(Tk) - pb.itab_u0) * pb.itab_inv_h;
             if (x >= (double)pb.f_desc[f].r_min && x < (double)pb.itab_m) {
-                S = exp_scaled<false>(interp_log_band_sum(pb, -1, pb.f_desc[f].ioff, x) * kInvLn2N, et);
+                S = exp_scaled<false>(interp_log_band_sum(pb, -1, f, x) * kInvLn2N, et);
                 done = true;
             }
         }
@@ -1528,7 +1566,7 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
     const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     double* exptab = reinterpret_cast<double*>(smem);
-    double* red = exptab + kExpTabSize;                                     // 4 * NPARTS wave sums (16 reserved)
+    double* red = exptab + kExpTabSize;                                     // 4 wave sums per part (32 reserved)
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
     const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
     const int itab_at = pb.n_itab_lds > 0
@@ -2206,7 +2244,14 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     // column each and round -- one part per 256 columns; else two parts up to 16 chunks of points, then one per 8
     // (measured on the 1024-walker, 3000-point fit in round 1: 2 parts 52 us/step, 4 parts 61, 8 parts 83)
     int n_parts = std::min(n_chunks_all, std::min(kMaxParts, std::max(2, (n_chunks_all + 7) / 8)));
-    if (epochs_ahead) n_parts = std::min(kMaxParts, std::max(n_cols > 64 ? 2 : 1, (n_cols + kBlock - 1) / kBlock));
+    if (epochs_ahead) {
+        // ... or, beyond kMaxParts x 256 columns, one part per 256 r columns with the smallest r that fits: a part's
+        // 256 lanes then make r full rounds (3000 single-point columns: 6 parts of 500, not 8 of 375 whose second round
+        // is half empty)
+        int rounds = 1;
+        while ((n_cols + kBlock * rounds - 1) / (kBlock * rounds) > kMaxParts) ++rounds;
+        n_parts = std::max(n_cols > 64 ? 2 : 1, (n_cols + kBlock * rounds - 1) / (kBlock * rounds));
+    }
     if (const char* env = std::getenv("LCF_PARTS"))
         n_parts = std::max(1, std::min(std::min(epochs_ahead ? n_cols : n_chunks_all, kMaxParts), std::atoi(env)));
     std::vector<int> part_start(kMaxParts + 1, N), part_col0(kMaxParts + 1, n_cols);
@@ -3022,7 +3067,7 @@ bool solo_eligible(const lcf_sampler* s) {
     // (and light curves without shared epochs -- thermal state per point, inside the point loop -- keep k_fused too: there
     // the serial head's registers on top of the point loop's do not fit 128 without spilling)
     return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.use_therm &&
-           e->dp.tab_in_lds && e->dp.n_parts <= 4 && solo_lds_bytes(e) <= kLdsPerCU;
+           e->dp.tab_in_lds && e->dp.n_parts <= kMaxParts && solo_lds_bytes(e) <= kLdsPerCU;
 }
 
 // The model-specialised kernels (k_solo / k_pop <..., MODEL>) take engines of the shape the benchmarks have: a power-law

@@ -321,8 +321,9 @@ def test_chain_matches_oracle_on_a_multiband_grid(model_name):
 
 def test_long_light_curve_one_launch_and_phases():
     """186 000 points in 31 000 epochs, 8 parts of ~3900 columns each: the thermal states are the lanes' own (no LDS
-    budget per epoch any more), so the run is one launch per half-step (k_fused: 8 parts) -- and the same chain as the
-    separate phases (k_step + k_points), bit for bit; the likelihoods of the final ensemble against the oracle."""
+    budget per epoch any more), so the run is one launch per half-step (k_solo: each half of the workgroup takes four of
+    the 8 parts) -- and the same chain as the separate phases (k_step + k_points), bit for bit; the likelihoods of the
+    final ensemble against the oracle."""
     from lightcurve_fitting_amd.engine import NativeSampler
     rng = np.random.default_rng(99)
     epochs = np.sort(rng.uniform(0.4, 30., 31000))
@@ -341,7 +342,7 @@ def test_long_light_curve_one_launch_and_phases():
     assert a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
     a.set_state(x0)
     a.run(0, 3, 'random', True)
-    assert a.last_run_kernel() == 'fused'
+    assert a.last_run_kernel() == 'solo'
     b = NativeSampler(eng, 16, 5)
     b.set_state(x0)
     b.begin(0, 3, 'random', True)

@@ -315,3 +315,28 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
     for k in pops:
         f = blocks[k]
         assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0 and int(f['Occupancy']) >= 4, (k, f)
+
+
+def test_roofline_basis_is_generated_by_the_build():
+    """bench.py's roofline.frac is computed from instruction counts that the BUILD took from the ISA of the library
+    (csrc/liblcf_hip.isa.json, tools/isa_count.py) -- not from constants typed into bench.py: the report must exist next
+    to the library, hold plausible counts, be what bench.isa_counts() returns, and bench.py must hold no per-unit
+    float64 instruction constant of its own."""
+    import json
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(os.path.dirname(E.__file__), 'csrc', 'liblcf_hip.isa.json')
+    if not os.path.exists(path):
+        pytest.skip('no ISA report next to the library (built without the Makefile)')
+    doc = json.load(open(path))
+    assert 60 <= doc['quad_main'] <= 100 and doc['quad_main'] <= doc['quad_safe']
+    assert 18 <= doc['point_lean'] <= 40 and 40 <= doc['log_lean'] <= doc['state_lean'] <= 160
+    assert 'k_solo' in doc['kernels']['lean'] and 'k_solo' in doc['kernels']['generic']
+    sys.path.insert(0, root)
+    import bench
+    counts, note = bench.isa_counts()
+    assert note is None and counts == {k: float(doc[k]) for k in counts}
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert not re.search(r'VALU_PER_(QUAD_F64|POINT|EPOCH)\w*\s*=', src)
