@@ -163,6 +163,21 @@ __device__ __forceinline__ double interp_log_band_sum(const DevProblem& pb, int 
 // the unstaged instantiations, so that it costs the staged kernels no registers.
 // ITAB: the instantiation may meet log-space states (engines with shared epochs only: with the thermal state inside the
 // point loop the interpolated path's registers do not fit next to it).
+// The factors a companion-shocking model applies per filter (models.py:909-917): shock factor x the filter's Kasen
+// parameter, its SiFTO parameter, its time shift -- from the fourth entry of the filter's descriptor and the proposal.
+__device__ __forceinline__ void companion_factors(const double2 fd3, const double* __restrict__ c, const double* __restrict__ p,
+                                                  double& kfac, double& sfac, double& dt) {
+    const long long ks = __double_as_longlong(fd3.x);   // {kpar, spar}, dtpar
+    const int kp = (int)ks, sp = (int)(ks >> 32), dp = (int)__double_as_longlong(fd3.y);
+    kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
+    sfac = sp >= 0 ? p[sp] : 1.;
+    dt = dp >= 0 ? p[dp] : 0.;
+}
+// shock component x factor + template x factor: ONE expression, so that every path contracts it the same way
+__device__ __forceinline__ double companion_combine(double shock, double kfac, double tmpl, double sfac) {
+    return shock * kfac + tmpl * sfac;
+}
+
 // MODEL > 0: compile-time model of an engine whose interpolants are all proved from their first interval
 // (DevProblem::itab_uniform) and which fits no sigma -- the kernels specialised for the benchmark shapes.
 template <int VARIANT, bool STAGED, bool ITAB, int MODEL = 0>
@@ -224,12 +239,10 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
     if (!by_table) yfit = (pref != pref) ? pref : pref * S;
     if (model == kShockCooling3) yfit *= c[5];  // models.py:495
     if (model >= kCompanion && model <= kCompanion3) {  // models.py:909-917, 977-980, 1040-1045
-        const long long ks = __double_as_longlong(fd[3].x);   // {kpar, spar} and dtpar of the filter's descriptor
-        const int kp = (int)ks, sp = (int)(ks >> 32), dp = (int)__double_as_longlong(fd[3].y);
-        const double kfac = c[5] * (kp >= 0 ? p[kp] : 1.);
-        const double sfac = sp >= 0 ? p[sp] : 1.;
-        const double dt = dp >= 0 ? p[dp] : 0.;
-        const double x = (t_in - c[3] - dt) / c[4];
+        double kfac, sfac, dt;
+        companion_factors(fd[3], c, p, kfac, sfac, dt);
+        // (the stretch as a reciprocal, taken once per column by the column paths: (t - t_peak - dt) / s within a rounding)
+        const double x = (t_in - c[3] - dt) * (1. / c[4]);
         double tmpl;
         if (pb.knot_h > 0.) {   // integer-day knots: interval computed; coefficients from LDS where they are staged
             extern __shared__ __align__(16) unsigned char smem[];
@@ -244,7 +257,7 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
         } else {
             tmpl = spline_eval(pb.knots, pb.n_knots, pb.spl + (size_t)filt * (pb.n_knots - 1) * 4, x, pb.knot_inv_h);
         }
-        yfit = yfit * kfac + tmpl * sfac;
+        yfit = companion_combine(yfit, kfac, tmpl, sfac);
     }
     return yfit;
 }
@@ -315,6 +328,33 @@ __device__ __forceinline__ void interp_columns(const DevProblem& pb, int lds_at,
     // (|ln R_bb^2| <= 600 and |ln S| < 100: the exponent can be added as an integer)
 #pragma unroll
     for (int m = 0; m < M; ++m) yfit[m] = exp_scaled<false>(fma(g[m], kInvLn2N, lnr2k), et);
+}
+
+// M filters of one dense column of a COMPANION-SHOCKING model side by side: the Kasen blackbody through the interpolants
+// (interp_columns) and the SiFTO template from the staged splines (integer-day knots), combined with the filters' factors;
+// returns the M squared scaled residuals' sum.  The arithmetic is point_model's, operation for operation.
+template <int M>
+__device__ __forceinline__ double companion_columns(const DevProblem& pb, int itab_at, int spl_at, const double2* fd2,
+                                                    const double* __restrict__ p, const double* __restrict__ c, int f0,
+                                                    int row, double s, double lnr2k, double t_in, double inv_s,
+                                                    const ExpTab et, const double2* __restrict__ yd, int nc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 o[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) o[m] = yd[(size_t)(f0 + m) * nc];
+    double shock[M];
+    interp_columns<M, true>(pb, itab_at, f0, row, s, lnr2k, et, shock);
+    double acc = 0.;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        double kfac, sfac, dt;
+        companion_factors(fd2[kFdD2 * (f0 + m) + 3], c, p, kfac, sfac, dt);
+        const double x = (t_in - c[3] - dt) * inv_s;
+        const double tmpl = spline_eval_uniform(pb, reinterpret_cast<const double2*>(smem + spl_at) + (f0 + m) * (pb.n_knots - 1) * 2, x);
+        const double q = (o[m].x - companion_combine(shock[m], kfac, tmpl, sfac)) * o[m].y;
+        acc = fma(q, q, acc);
+    }
+    return acc;
 }
 
 // What a lane needs of its FIRST column before any arithmetic: the observation time and (dense columns of up to kPreK
@@ -518,6 +558,10 @@ __device__ inline double epochs_loop(const DevProblem& pb, int part, const doubl
     const int lane = vtid & 63, v64 = __builtin_amdgcn_readfirstlane(vtid & ~63);
     const bool by_itab = MODEL ? true : VARIANT != 0 && pb.use_itab;
     const bool fast_kind = columns_fast_kind<MODEL>(pb, by_itab);
+    // companion-shocking models with dense columns, interpolants AND template splines staged (integer-day knots)
+    const bool companion_fast = !MODEL && LDS_TAB && by_itab && pb.em_dense && pb.itab_uniform && !pb.use_sigma &&
+                                pb.model >= kCompanion && pb.model <= kCompanion3 && itab_at >= 0 && pb.n_spl_lds > 0 &&
+                                pb.knot_h > 0.;
     // (generic kernels only: compiled into the model-specialised ones as well it cost them their registers -- 2 to 34
     // spilled -- and photometry without shared epochs ran no faster there, 25.7 against 26.0 us)
     const bool ragged_fast = !MODEL && by_itab && !pb.em_dense && pb.itab_uniform && !pb.use_sigma &&
@@ -568,6 +612,27 @@ __device__ inline double epochs_loop(const DevProblem& pb, int part, const doubl
                 const double q = (o.x - exp_scaled<false>(fma(L, kInvLn2N, lnr2k), et)) * o.y;
                 acc = filt >= 0 ? fma(q, q, acc) : acc;
             }
+            term += live ? acc : 0.;
+            continue;
+        }
+        if (companion_fast && __builtin_amdgcn_ballot_w64(__double2hiint(x) < 0) == 0) {
+            // dense columns of a companion-shocking model, everything staged: groups of three filters side by side
+            const int row = 8 * (int)x;
+            const double s = fma(__builtin_amdgcn_fract(x), 2., -1.);
+            const double lnr2k = pr * kInvLn2N, inv_s = 1. / c[4];
+            const int spl_at = itab_at + pb.n_itab_lds * (int)sizeof(double), nf = pb.em_k, ncols = pb.em_cols;
+            const double2* fd2 = reinterpret_cast<const double2*>(fdesc);
+            const double2* yd = pb.em_yd + col;
+            double acc = 0.;
+            int f = 0;
+#pragma unroll 1
+            for (; f + 3 <= nf; f += 3)
+                acc += companion_columns<3>(pb, itab_at, spl_at, fd2, p, c, f, row, s, lnr2k, t_in, inv_s, et, yd, ncols);
+            if (f + 2 <= nf) {
+                acc += companion_columns<2>(pb, itab_at, spl_at, fd2, p, c, f, row, s, lnr2k, t_in, inv_s, et, yd, ncols);
+                f += 2;
+            }
+            if (f < nf) acc += companion_columns<1>(pb, itab_at, spl_at, fd2, p, c, f, row, s, lnr2k, t_in, inv_s, et, yd, ncols);
             term += live ? acc : 0.;
             continue;
         }

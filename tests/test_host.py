@@ -306,8 +306,8 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
         assert int(f['ScratchSize']) == 0 and int(f['VGPRs Spill']) == 0, (k, f)
         # scalar registers spill into lanes of a vector register (cheap, but every spill is an instruction in a kernel
         # that is bound by instruction issue): the benchmark kernels stay under one register's worth, the generic ones
-        # -- every model's arithmetic behind run-time switches -- under four
-        assert int(f['SGPRs Spill']) <= (64 if k in special else 224), (k, f)
+        # -- every model's arithmetic and both column fast paths behind run-time switches -- under four
+        assert int(f['SGPRs Spill']) <= (64 if k in special else 256), (k, f)
         assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
     # population mode's one launch per half-step, in the dimensions with their own instantiation
     pops = [k for k in blocks if re.search(r'k_popILi[4568]ELi1ELi4ELi[012]E', k)]
