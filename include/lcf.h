@@ -217,18 +217,23 @@ double lcf_sampler_last_run_ms(const lcf_sampler* s);
 int32_t lcf_sampler_one_launch(const lcf_sampler* s);
 /* Which kernels a single-GPU run (lcf_sampler_run / _run_async) may use for a half-step.  All of them produce the
  * same chain bit for bit; the choice exists for tests and measurements.
- *   AUTO:   one workgroup per proposal that also accepts / rejects (k_solo) where a proposal's parts fit one
- *           workgroup, else one workgroup per (proposal, part) (k_fused), else proposal + likelihood launches
+ *   AUTO:   one workgroup per proposal that also accepts / rejects, resident for a whole block of half-steps
+ *           (k_solo_run: ONE launch per up to 60 steps, rows handed from workgroup to workgroup through a board of
+ *           tagged rows in device memory) where a proposal's parts fit one workgroup; else one workgroup per
+ *           (proposal, part) and launch (k_fused); else proposal + likelihood launches
+ *   SOLO:   as AUTO, but one launch per half-step (k_solo)
  *   FUSED:  never k_solo        PHASES: always proposal + likelihood launches
- * Returns in *used (optional) what a run would use now: 2 = k_solo, 1 = k_fused, 0 = separate launches. */
-enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2 };
+ * Returns in *used (optional) what a run would use now: 3 = k_solo_run, 2 = k_solo, 1 = k_fused, 0 = separate launches.
+ * (LCF_NO_RUN_KERNEL=1 in the environment: AUTO never picks k_solo_run -- for several processes sharing one GPU, whose
+ * resident launches could keep each other's workgroups out.) */
+enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2, LCF_HALF_STEP_SOLO = 3 };
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used);
 
 /* What the half-steps of the sampler's last run were executed by (-1: no run yet): separate proposal / likelihood
  * launches, k_fused, k_solo; for lcf_population_run one launch per half-step for all transients (k_pop: a workgroup per
  * four proposals, accept test included) or the two launches k_step_multi + k_points_multi. */
 enum { LCF_KERNEL_PHASES = 0, LCF_KERNEL_FUSED = 1, LCF_KERNEL_SOLO = 2, LCF_KERNEL_POPULATION = 3,
-       LCF_KERNEL_POPULATION_PHASES = 4 };
+       LCF_KERNEL_POPULATION_PHASES = 4, LCF_KERNEL_RUN = 5 /* k_solo_run: a block of half-steps per launch */ };
 int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new

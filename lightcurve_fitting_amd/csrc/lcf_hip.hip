@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -40,6 +41,12 @@
 #endif
 #ifndef LCF_KPRE_SOLO
 #define LCF_KPRE_SOLO 2  // the same in the one-workgroup-per-proposal kernel (4: 3.73e7 walker-steps/s, 3: 3.74e7, 2: 3.78e7)
+#endif
+#ifndef LCF_RUN_AGENT
+#define LCF_RUN_AGENT 1       // (experiment) 0: the board of a one-launch run is polled and posted at system scope
+#endif
+#ifndef LCF_RUN_KEEP_COLS
+#define LCF_RUN_KEEP_COLS 1   // 1: k_solo_run keeps the lanes' first columns in registers across half-steps (spills)
 #endif
 #ifndef LCF_FIRST_BLOCK
 #define LCF_FIRST_BLOCK 32  // steps in the first block of draw records of a run (the later ones: up to 256)
@@ -973,6 +980,7 @@ struct DevSampler {
     unsigned long long* board;
     unsigned long long* peer_board[kMaxPeers];
     int n_board_ranks, board_rank;
+    int ring, run_mode;   // versions a board keeps (a power of two); 1: the board of a one-launch run (k_solo_run), no peers
     // Bound of every wait for another rank (mailbox entries, board rows, progress words), in ticks of the 100 MHz wall
     // clock: peer_wait_ticks().  A rank's stream holds only a few ms of launches, so a host that stalls longer than
     // this on ONE rank ends the run on ALL of them -- the default is therefore seconds, not the 0.5 s of round 2.
@@ -1399,26 +1407,41 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
 // NEXT launch: stream order proves that the launch before it is complete): half-steps G - 1 and G are the only ones in
 // flight anywhere, they read versions >= G - 3 and write G and G + 1, so eight versions are never overrun.
 constexpr int kRing = 8;
+// One-launch runs (k_solo_run): a launch covers at most kRunSpan half-steps, reads versions >= G - 3 and writes G + 1:
+// kRunRing versions are never overrun however far the workgroups of a launch drift apart.
+constexpr int kRunRing = 128;
+constexpr int kRunSpan = 64;
 constexpr int kBoardTail = kMaxPeers + 1 + 4;   // 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis
 
 __device__ inline size_t board_rows_words(const DevSampler& sm) {
-    return (size_t)kRing * sm.n_walkers * (sm.n_dim + 2) * 2;   // 8-byte words
+    return (size_t)sm.ring * sm.n_walkers * (sm.n_dim + 2) * 2;   // 8-byte words
 }
 __device__ inline unsigned long long* board_entry(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid,
                                                   int col) {
-    return board + 2 * ((((size_t)(tag & (kRing - 1)) * sm.n_walkers) + wid) * (sm.n_dim + 2) + col);
+    return board + 2 * ((((size_t)(tag & (unsigned int)(sm.ring - 1)) * sm.n_walkers) + wid) * (sm.n_dim + 2) + col);
 }
 __device__ inline unsigned int* board_progress(unsigned long long* board, const DevSampler& sm) {
     return reinterpret_cast<unsigned int*>(board + board_rows_words(sm));
 }
+// AGENT: the board of a one-launch run lives in this GPU's ordinary memory and is shared by its own workgroups only:
+// device scope (the loads and stores meet behind the XCDs' L2s) instead of system scope.
+template <bool AGENT = false>
 __device__ inline void board_post(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid, int col, double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
     unsigned long long* p = board_entry(board, sm, tag, wid, col);
-    __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (AGENT) {
+        __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+template <bool AGENT = false>
 __device__ inline bool board_aborted(const DevSampler& sm) {
-    return __hip_atomic_load(board_progress(sm.board, sm) + kMaxPeers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    const unsigned int* flag = board_progress(sm.board, sm) + kMaxPeers;
+    return (AGENT ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                  : __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
 }
 // (what: 1 = a row, a = tag, b = walker, c = column; 2 = the progress words, a = half-step, b = rank that is behind)
 __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsigned int a, unsigned int b, unsigned int c) {
@@ -1433,16 +1456,19 @@ __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsi
 }
 // The number with tag `tag` from this rank's board, once it is there (bounded wait: DevSampler::wait_ticks, then the launch is aborted
 // and the run ends with an error; NaN after an abort).
+template <bool AGENT = false>
 __device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col) {
     const unsigned long long* p = board_entry(sm.board, sm, tag, wid, col);
     const unsigned long long t0 = wall_clock64();
     for (int spin = 0;; ++spin) {
-        const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long a = AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long b = AGENT ? __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned int)(a >> 32) == tag && (unsigned int)(b >> 32) == tag)
             return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
         if ((spin & 15) == 15) {
-            if (board_aborted(sm)) return qnan();
+            if (board_aborted<AGENT>(sm)) return qnan();
             if (wall_clock64() - t0 > sm.wait_ticks) {
                 board_abort(sm, 1u, tag, (unsigned int)wid, (unsigned int)col);
                 return qnan();
@@ -1511,7 +1537,7 @@ struct HeadRows {
     PriorDev prior;         // lane d: the prior of parameter d
 };
 
-template <int ND, bool BOARD = false>
+template <int ND, int BOARD = 0>
 __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
                                            HeadRows<ND>& h, long long G = 0, long long g_run0 = 0) {
     constexpr int kD = ND > 0 ? ND : kMaxDim;
@@ -1523,7 +1549,7 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
         const bool own = lane >= 16;
         const int col = own ? lane - 16 : lane;
         if (own ? col <= nd + 1 : col < nd)
-            h.got = board_take(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
+            h.got = board_take<BOARD == 2 && LCF_RUN_AGENT>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
     }
     h.lp_i = BOARD ? lane_value(h.got, 16 + nd) : sm.LP[dr.wid];
 #pragma unroll
@@ -1535,7 +1561,7 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
     if (lane < pb.n_dim && pb.has_priors) h.prior = pb.priors[lane];
 }
 
-template <int ND, bool BOARD = false, int MODEL = 0>
+template <int ND, int BOARD = 0, int MODEL = 0>
 __device__ __forceinline__ void proposal_head(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
                                               double* __restrict__ sc, double* __restrict__ sq, double* __restrict__ sx,
                                               const HeadRows<ND>& h) {
@@ -1621,11 +1647,14 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // NPARTS = 8: three or four parts again, but FOUR groups of 256 threads, one part each at the same time (1024 threads):
 // for launches of at most one workgroup per CU -- a rank's share of a strongly scaled ensemble, configs[2] on 8 GPUs:
 // 256 proposals -- where a second workgroup to overlap with does not exist and the parts of one proposal can.
-template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false, int MODEL = 0>
-__global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
-void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
-            const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// BOARD = 2: one half-step of a ONE-LAUNCH run (k_solo_run below): rows from / to this GPU's own board, the chain written
+// here; `first`: the workgroup's first half-step of the launch (tables staged, first columns fetched: both stay).
+// Returns true when the run is aborted (uniform over the workgroup).
+template <int ND, int VARIANT, bool THERM, int NPARTS, int BOARD, int MODEL>
+__device__ __forceinline__ bool solo_half_step(const DevProblem* __restrict__ pbp, const DevSampler& sm, long long row,
+                                               const DrawRec* __restrict__ draws, const DrawRec* draws_next, long long G,
+                                               long long g_run0, int i, unsigned char* smem, ColumnOperands& first_col,
+                                               bool first, bool write_state, const int tid) {
     // The problem is read through a constant-address-space pointer: scalar loads where a field is used, instead of
     // 700 bytes of kernel arguments preloaded into (and spilled from) scalar registers.
     typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
@@ -1644,19 +1673,18 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     constexpr int kThreads = kBlock * kGroups;
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
-    const int tid = threadIdx.x, i = blockIdx.x + (BOARD ? slot_lo : 0);
     const bool reddened = !MODEL && pb.model == kShockCooling3;
     LCF_STAMP(0, 0);
 #ifdef LCF_STAMPS
     if (tid == 0 && blockIdx.x < 1024) g_wall[((G & 1) * 1024 + blockIdx.x) * 2] = wall_clock64();
 #endif
     const DrawRec dr = draws[i];     // wave-uniform
-    if (BOARD && blockIdx.x == 0 && tid < sm.n_board_ranks)
+    if (BOARD == 1 && blockIdx.x == 0 && tid < sm.n_board_ranks)
         // This launch runs, so every launch in front of it in the stream has finished: tell every rank that this rank
         // is through with all half-steps before G (stream order does the counting; no atomics).
         __hip_atomic_store(board_progress(sm.peer_board[tid], sm) + sm.board_rank, (unsigned int)G, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
-    if (dr.wid < 0) return;          // an odd ensemble's smaller colour leaves its last slot empty
+    if (dr.wid < 0) return false;    // an odd ensemble's smaller colour leaves its last slot empty
     LCF_STAMP(0, 1);
     // the operands of this thread's first column (of the first part its half of the workgroup walks): requested now,
     // needed behind the barrier
@@ -1664,15 +1692,14 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     // same path -- start once they are out: rows + proposal 3.8 k cycles with everything requested at once, 2.1 k alone)
     // (model-specialised kernels only: the generic ones need the registers for the point-by-point path)
     constexpr bool kFetch = MODEL != 0;
-    ColumnOperands first_col;
     if (tid < 64) {
         HeadRows<ND> rows;
         head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0);
-        if (kFetch) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
+        if (kFetch && (first || !LCF_RUN_KEEP_COLS)) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
     } else {
         if (LCF_HEAD_START > 0) __builtin_amdgcn_s_sleep(LCF_HEAD_START);
-        if (kFetch) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
+        if (kFetch && (first || !LCF_RUN_KEEP_COLS)) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
         // (a hint only: nothing depends on the value or on the placement).
@@ -1681,9 +1708,10 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
             (void)nxt[0];
             (void)nxt[sizeof(DrawRec) / sizeof(int) - 1];
         }
-        if (!reddened) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
+        if (!reddened && first) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
         LCF_STAMP(1, 11);
-        if (BOARD && tid < 128) {
+        if (BOARD == 2 && tid == 64) sctl[0] = board_aborted<LCF_RUN_AGENT != 0>(sm) ? 1 : 0;   // (in the shadow of the head)
+        if (BOARD == 1 && tid < 128) {
             // In the shadow of the head: has every rank finished half-step G - 2 (lane = rank)?  has this rank given up?
             const int lane = tid - 64;
             const unsigned int* progress = board_progress(sm.board, sm);
@@ -1709,7 +1737,7 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
     }
     __syncthreads();
     LCF_STAMP(0, 6);
-    if (BOARD && sctl[0] != 0) return;   // (uniform: everybody reads the same word)
+    if (BOARD && sctl[0] != 0) return true;   // (uniform: everybody reads the same word)
     const double lpr = sc[kNCoef];
     double term = 0.;
     const bool excluded = lpr == -INFINITY;  // prior excludes the proposal: likelihood skipped (fitting.py:125)
@@ -1784,7 +1812,7 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
         // ---- accept / reject by wave 0; lanes 0 .. nd+1 post the row (position, log-posterior, acceptance count) on every
         // rank's board; this rank's X / LP / counts follow for its own walkers (the others' come from the board when
         // the run ends, and the chain is written from the board)
-        if (tid >= 64) return;
+        if (tid >= 64) return false;
         double nlp = -INFINITY;
         if (!excluded) {
             double sum = pb.use_sigma ? 0. : pb.log_norm_const;
@@ -1796,21 +1824,33 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
         const double count = sx[kMaxDim + 1] + (ok ? 1. : 0.);
         if (tid <= nd + 1) {
             const double v = tid < nd ? (ok ? sq[tid] : sx[tid]) : tid == nd ? (ok ? nlp : lp_i) : count;
+            if (BOARD == 2) {
+                board_post<LCF_RUN_AGENT != 0>(sm.board, sm, (unsigned int)(G + 1), dr.wid, tid, v);
+            } else {
 #pragma unroll
-            for (int r = 0; r < kMaxPeers; ++r)
-                if (r < sm.n_board_ranks) board_post(sm.peer_board[r], sm, (unsigned int)(G + 1), dr.wid, tid, v);
-            if (tid < nd)
-                sm.X[(size_t)dr.wid * nd + tid] = v;
-            else if (tid == nd)
-                sm.LP[dr.wid] = v;
-            else
-                sm.nacc[dr.wid] = (long long)v;
+                for (int r = 0; r < kMaxPeers; ++r)
+                    if (r < sm.n_board_ranks) board_post(sm.peer_board[r], sm, (unsigned int)(G + 1), dr.wid, tid, v);
+            }
+            // (a one-launch run writes the state in its last step only: every walker moves exactly once there, while two
+            // moves of a walker in one launch come from different workgroups, and whose store reaches memory last is open)
+            if (BOARD != 2 || write_state) {
+                if (tid < nd)
+                    sm.X[(size_t)dr.wid * nd + tid] = v;
+                else if (tid == nd)
+                    sm.LP[dr.wid] = v;
+                else
+                    sm.nacc[dr.wid] = (long long)v;
+            }
+            if (BOARD == 2 && sm.store_chain) {   // (one GPU: every walker's row is decided here)
+                if (tid < nd) sm.chain[((size_t)row * sm.n_walkers + dr.wid) * nd + tid] = v;
+                else if (tid == nd) sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = v;
+            }
         }
         if (tid == 0 && nlp != nlp) atomicOr(sm.err, 1);
         LCF_STAMP(0, 10);
-        return;
+        return false;
     }
-    if (tid != 0) return;
+    if (tid != 0) return false;
     // ---- accept / reject and commit (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move)
     double nlp = -INFINITY;
     if (!excluded) {
@@ -1839,6 +1879,58 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
 #ifdef LCF_STAMPS
     if (blockIdx.x < 1024) g_wall[((G & 1) * 1024 + blockIdx.x) * 2 + 1] = wall_clock64();
 #endif
+    return false;
+}
+
+template <int ND, int VARIANT, bool THERM, int NPARTS, bool BOARD = false, int MODEL = 0>
+__global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
+void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long row, const DrawRec* __restrict__ draws,
+            const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    ColumnOperands first_col;
+    solo_half_step<ND, VARIANT, THERM, NPARTS, BOARD ? 1 : 0, MODEL>(pbp, sm, row, draws, draws_next, G, g_run0,
+                                                                     blockIdx.x + (BOARD ? slot_lo : 0), smem, first_col, true,
+                                                                     true, threadIdx.x);
+}
+
+// ---- a whole run (or a block of it) in ONE launch -------------------------------------------------------------------
+// The workgroups stay: workgroup b takes slot b (b + gridDim.x, ...) of half-step G0, then of G0 + 1, ... -- no kernel
+// boundary between half-steps, tables staged and first columns fetched once per launch, and nothing makes two
+// workgroups of a CU run in step, so one's serial head overlaps the other's columns.  What a half-step needs from an
+// earlier one -- the rows of its walker and of the partner -- comes from a board of tagged rows in this GPU's memory,
+// exactly as between the ranks of a row-board run (BOARD = 2): a head polls for the version its draw record names.
+// Every wait is for a row of an EARLIER half-step, so the launch makes progress as long as all its workgroups are
+// resident at once: the host launches no more than the device holds.  The ring keeps more versions than a launch has
+// half-steps (DevSampler::ring), so no workgroup can overrun a version another one still waits for.
+template <int ND, int VARIANT, bool THERM, int NPARTS, int MODEL>
+__global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
+void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long long rel0, const DrawRec* __restrict__ draws0,
+                long long g_run0, int n_hs, long long state_from) {
+    extern __shared__ __align__(16) unsigned char smem[];
+#if LCF_RUN_KEEP_COLS
+    ColumnOperands first_col;
+#endif
+    bool first = true;
+#pragma unroll 1
+    for (int h = 0; h < n_hs; ++h) {
+        const DrawRec* draws = draws0 + (size_t)h * sm.n_half;
+#pragma unroll 1
+        for (int i = blockIdx.x; i < sm.n_half; i += gridDim.x) {
+            if (draws[i].wid < 0) continue;   // (uniform) an odd ensemble's smaller colour leaves its last slot empty
+#if !LCF_RUN_KEEP_COLS
+            ColumnOperands first_col;         // (re-fetched per half-step, from L2: 26 registers that need not live on)
+#endif
+            // the record this workgroup needs next: its next slot of this half-step, else its first of the next one
+            const bool more = i + (int)gridDim.x < sm.n_half;
+            const DrawRec* hint = more ? draws + gridDim.x : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
+            const int tid = threadIdx.x;
+            if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pbp, sm, (rel0 + h) >> 1, draws, hint,
+                                                                     g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
+                                                                     rel0 + h >= state_from, tid))
+                return;
+            first = false;
+        }
+    }
 }
 
 // State of the sampler as 8-byte words into (mapped, pinned) host memory: [error flag | X | LP | n_accepted].
@@ -2852,6 +2944,12 @@ struct lcf_sampler {
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
     void* board_mem = nullptr;               // this rank's row board (uncached device memory), see DevSampler
     std::vector<void*> board_opened;         // peers' boards mapped through IPC
+    void* run_board_mem = nullptr;           // the board of one-launch runs (k_solo_run): kRunRing versions, this GPU only
+    int run_capacity = -1;                   // workgroups of k_solo_run the device holds at once (-1: not asked yet)
+    size_t run_board_bytes() const {
+        return (size_t)kRunRing * ds.n_walkers * (ds.n_dim + 2) * 2 * sizeof(unsigned long long) +
+               (size_t)kBoardTail * sizeof(unsigned int);
+    }
     size_t board_bytes() const {
         return (size_t)kRing * ds.n_walkers * (ds.n_dim + 2) * 2 * sizeof(unsigned long long) +
                (size_t)kBoardTail * sizeof(unsigned int);
@@ -2881,6 +2979,7 @@ struct lcf_sampler {
         if (mailbox) hipFree(mailbox);
         for (void* p : board_opened) hipIpcCloseMemHandle(p);
         if (board_mem) hipFree(board_mem);
+        if (run_board_mem) hipFree(run_board_mem);
         if (snap) hipHostFree(snap);
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
@@ -3131,8 +3230,9 @@ bool solo_eligible(const lcf_sampler* s) {
     // (the libm band sum, variant 0, exists to mirror the reference instruction for instruction: it keeps k_fused)
     // (and light curves without shared epochs -- thermal state per point, inside the point loop -- keep k_fused too: there
     // the serial head's registers on top of the point loop's do not fit 128 without spilling)
-    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && e->dp.variant != 0 && e->dp.use_therm &&
-           e->dp.tab_in_lds && e->dp.n_parts <= kMaxParts && solo_lds_bytes(e) <= kLdsPerCU;
+    return !disabled && (s->half_step_kernel == LCF_HALF_STEP_AUTO || s->half_step_kernel == LCF_HALF_STEP_SOLO) &&
+           e->dp.variant != 0 && e->dp.use_therm && e->dp.tab_in_lds && e->dp.n_parts <= kMaxParts &&
+           solo_lds_bytes(e) <= kLdsPerCU;
 }
 
 // The model-specialised kernels (k_solo / k_pop <..., MODEL>) take engines of the shape the benchmarks have: a power-law
@@ -3206,6 +3306,96 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 #undef LCF_SOLO6
     LCF_HIP(hipGetLastError());
     return leave_half_step(s, st);
+}
+
+// ---- a block of half-steps in ONE launch (k_solo_run) ---------------------------------------------------------------
+// Runs of one GPU whose half-steps k_solo can execute.  The launch's workgroups wait for each other's rows, so they must
+// all be resident at once: the grid is what the device holds (occupancy x CUs; each workgroup then takes several slots
+// of a half-step), and a process keeps ONE such launch in flight per device (`g_run_busy`): a second sampler's run
+// enqueued meanwhile on another stream takes a launch per half-step.
+bool run_eligible(const lcf_sampler* s) {
+    static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0;
+}
+
+struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; };
+RunBusy g_run_busy[64];
+std::mutex g_run_mutex;
+
+// May a one-launch run go on stream `st` of device `dev` now?  (Yes unless another stream's is still in flight.)
+bool run_claim(int dev, hipStream_t st) {
+    if (dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(g_run_mutex);
+    RunBusy& b = g_run_busy[dev];
+    if (b.used && b.stream != st && hipEventQuery(b.ev) == hipErrorNotReady) return false;
+    if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) return false;
+    b.stream = st;
+    b.used = true;
+    return true;
+}
+void run_release(int dev, hipStream_t st) {   // behind the last launch of the run
+    std::lock_guard<std::mutex> lock(g_run_mutex);
+    (void)hipEventRecord(g_run_busy[dev].ev, st);
+}
+
+template <class K>
+lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
+    if (s->run_capacity >= 0) return LCF_OK;
+    if (lds > 64 * 1024)
+        LCF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
+    int per_cu = 0;
+    LCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+    s->run_capacity = per_cu * s->e->n_cus;
+    if (const char* env = std::getenv("LCF_RUN_GRID")) s->run_capacity = std::min(s->run_capacity, std::atoi(env));  // (tests)
+    return LCF_OK;
+}
+
+// Half-steps [rel, rel + n_hs) of the run, all inside the current block of draw records.
+lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
+    lcf_engine* e = s->e;
+    DevSampler rs = s->ds;
+    rs.board = static_cast<unsigned long long*>(s->run_board_mem);
+    rs.peer_board[0] = rs.board;
+    rs.n_board_ranks = 1;
+    rs.board_rank = 0;
+    rs.ring = kRunRing;
+    rs.run_mode = 1;
+    const DrawRec* draws = s->rows(rel);
+    const size_t lds = solo_lds_bytes(e);
+    const long long g_run0 = s->g_run0;
+    const long long state_from = 2 * (s->run_steps - 1);   // X / LP / counts: written by the run's last step
+    const int spec = specialised_model(e->dp);
+#define LCF_RUN5(ND, NP, M)                                                                                           \
+    do {                                                                                                              \
+        if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M>, kBlock * 2, lds)) return r;                \
+        if (s->run_capacity < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");              \
+        const dim3 grid((unsigned)std::min(s->ds.n_half, s->run_capacity));                                           \
+        hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
+                           g_run0, n_hs, state_from);                                                                 \
+    } while (0)
+#define LCF_RUN4(ND, NP)                                                                                              \
+    do {                                                                                                              \
+        if (ND == 5 && spec == kShockCooling) LCF_RUN5(5, NP, kShockCooling);                                         \
+        else if (ND == 4 && spec == kShockCooling2) LCF_RUN5(4, NP, kShockCooling2);                                  \
+        else LCF_RUN5(ND, NP, 0);                                                                                     \
+    } while (0)
+#define LCF_RUN(ND) do { if (e->dp.n_parts <= 2) LCF_RUN4(ND, 2); else LCF_RUN4(ND, 4); } while (0)
+    switch (s->ds.n_dim) {
+#ifndef LCF_DEV_BUILD
+        case 4: LCF_RUN(4); break;
+        case 6: LCF_RUN(6); break;
+        case 7: LCF_RUN(7); break;
+        case 9: LCF_RUN(9); break;
+#endif
+        case 5: LCF_RUN(5); break;
+        case 8: LCF_RUN(8); break;
+        default: LCF_RUN(0); break;
+    }
+#undef LCF_RUN
+#undef LCF_RUN4
+#undef LCF_RUN5
+    LCF_HIP(hipGetLastError());
+    return LCF_OK;
 }
 
 // Log-posteriors of the shard's proposals from their partial sums (sharded runs: the all-gather sends these).
@@ -3413,6 +3603,8 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     ds.key1 = (uint32_t)(seed >> 32);
     ds.a = a;
     ds.wait_ticks = peer_wait_ticks();
+    ds.ring = kRing;
+    ds.run_mode = 0;
     const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
     lcf_status st;
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
@@ -3518,10 +3710,10 @@ lcf_status lcf_sampler_accept(lcf_sampler* s, int64_t step, int32_t half, void* 
 }
 void* lcf_sampler_newlp_ptr(lcf_sampler* s) { return s ? s->ds.newlp[(s->g_next - 1) & 1] : nullptr; }
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used) {
-    if (!s || choice < LCF_HALF_STEP_AUTO || choice > LCF_HALF_STEP_PHASES)
+    if (!s || choice < LCF_HALF_STEP_AUTO || choice > LCF_HALF_STEP_SOLO)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad half-step kernel choice");
     s->half_step_kernel = choice;
-    if (used) *used = solo_eligible(s) ? 2 : fused_eligible(s) ? 1 : 0;
+    if (used) *used = run_eligible(s) ? 3 : solo_eligible(s) ? 2 : fused_eligible(s) ? 1 : 0;
     return LCF_OK;
 }
 
@@ -3557,9 +3749,20 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
         // the half-step the others gave up on: the ensemble must be set again, on every rank, before the next run)
         const double sec = (double)s->ds.wait_ticks / 1e8;
         unsigned int w[5] = {0, 0, 0, 0, 0};
-        if (s->board_mem)
+        const bool run = s->last_kernel == LCF_KERNEL_RUN && s->run_board_mem;
+        if (run)
+            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int),
+                      sizeof w, hipMemcpyDeviceToHost);
+        else if (s->board_mem)
             hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - 5 * sizeof(unsigned int), sizeof w,
                       hipMemcpyDeviceToHost);
+        if (run) {
+            char msg[260];
+            std::snprintf(msg, sizeof msg, "one-launch run: version %u of walker %u (column %u) was not posted within %.1f s: "
+                          "the launch's workgroups were not all resident (another process's persistent kernel on this "
+                          "GPU?); set the state again and run with LCF_NO_RUN_KERNEL=1", w[2], w[3], w[4], sec);
+            return fail(LCF_ERR_STATE, msg);
+        }
         if (w[0]) {
             char msg[200];
             if (w[1] == 1)
@@ -3926,10 +4129,43 @@ lcf_status lcf_sampler_run_rows(lcf_sampler* s, int64_t first_step, int64_t n_st
 lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
                                  const int32_t* perm, int32_t store_chain) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
-    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, !solo_eligible(s))) return st;
+    const bool one_launch = run_eligible(s) && n_steps > 0 && run_claim(s->e->device, s->e->stream);
+    if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain,
+                                      !solo_eligible(s) || run_eligible(s))) return st;
     hipStream_t st = s->e->stream;
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
+    if (one_launch) {   // the workgroups stay for a block of half-steps and hand each other rows (k_solo_run)
+        if (!s->run_board_mem) {
+            if (std::getenv("LCF_RUN_BOARD_UNCACHED"))   // (experiment)
+                LCF_HIP(hipExtMallocWithFlags(&s->run_board_mem, s->run_board_bytes(), hipDeviceMallocUncached));
+            else
+                LCF_HIP(hipMalloc(&s->run_board_mem, s->run_board_bytes()));
+            LCF_HIP(hipMemsetAsync(s->run_board_mem, 0, s->run_board_bytes(), st));   // tag 0: no version
+        }
+        s->last_kernel = LCF_KERNEL_RUN;
+        DevSampler rs = s->ds;
+        rs.board = static_cast<unsigned long long*>(s->run_board_mem);
+        rs.ring = kRunRing;
+        const long long cells = (long long)rs.n_walkers * (rs.n_dim + 2);
+        hipLaunchKernelGGL(k_board_init, dim3((unsigned)((std::max<long long>(cells, 5) + 255) / 256)), dim3(256), 0, st, rs,
+                           (unsigned int)s->g_run0);
+        LCF_HIP(hipGetLastError());
+        for (long long rel = 0; rel < 2 * n_steps;) {
+            if (lcf_status r = enter_half_step(s, rel, st)) return r;
+            const int64_t b = s->blk_current;
+            const long long end = 2 * (s->block_start(b) + s->block_len(b));
+            const int n = (int)std::min<long long>(kRunSpan, end - rel);
+            if (lcf_status r = launch_run(s, rel, n, st)) return r;
+            if (lcf_status r = leave_half_step(s, st)) return r;
+            rel += n;
+        }
+        s->g_next += 2 * n_steps;
+        LCF_HIP(hipEventRecord(s->ev1, st));
+        run_release(s->e->device, st);
+        if (lcf_status r = enqueue_snapshot(s)) return r;
+        return speculate_continuation(s, st);
+    }
     // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else
     // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
     const bool fused = fused_eligible(s);

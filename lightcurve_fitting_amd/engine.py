@@ -454,19 +454,21 @@ class NativeSampler:
         return bool(self._lib.lcf_sampler_one_launch(self._h))
 
     def last_run_kernel(self):
-        """What executed the half-steps of the last run: 'phases' | 'fused' | 'solo' | 'population' (one launch per
-        half-step for all transients of a population) | 'population-phases' (None: no run yet)."""
-        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases'}.get(
+        """What executed the half-steps of the last run: 'phases' | 'fused' | 'solo' | 'run' (k_solo_run: resident
+        workgroups, one launch per block of half-steps) | 'population' (one launch per half-step for all transients of
+        a population) | 'population-phases' (None: no run yet)."""
+        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run'}.get(
             self._lib.lcf_sampler_last_run_kernel(self._h))
 
     def set_half_step_kernel(self, choice='auto'):
-        """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'fused' | 'phases'; same chain bit
-        for bit).  Returns what a run uses now: 'solo' (one workgroup per proposal, accept test included), 'fused'
-        (one workgroup per proposal and part) or 'phases' (proposal + likelihood launches)."""
+        """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'solo' | 'fused' | 'phases'; same
+        chain bit for bit).  Returns what a run uses now: 'run' (one workgroup per proposal, accept test included,
+        resident for a block of half-steps), 'solo' (the same with a launch per half-step), 'fused' (one workgroup per
+        proposal and part) or 'phases' (proposal + likelihood launches)."""
         used = C.c_int32()
-        _check(self._lib.lcf_sampler_set_half_step_kernel(self._h, {'auto': 0, 'fused': 1, 'phases': 2}[choice],
+        _check(self._lib.lcf_sampler_set_half_step_kernel(self._h, {'auto': 0, 'fused': 1, 'phases': 2, 'solo': 3}[choice],
                                                           C.byref(used)))
-        return {2: 'solo', 1: 'fused', 0: 'phases'}[used.value]
+        return {3: 'run', 2: 'solo', 1: 'fused', 0: 'phases'}[used.value]
 
     def half_step_rows(self, step, half, lo, hi, stream=0):
         _check(self._lib.lcf_sampler_half_step_rows(self._h, int(step), int(half), int(lo), int(hi),

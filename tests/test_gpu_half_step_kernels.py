@@ -60,9 +60,9 @@ def test_states_outside_the_interpolants_take_the_general_path():
     x0 = pb['truth'] * (1 + 0.05 * rng.standard_normal((64, 5)))
     x0[::2, 4] = rng.uniform(0.405, 0.49, 32)      # epochs start at 0.4 d; the prior allows up to 0.5
     assert np.any(pb['t'].min() < x0[:, 4])
-    runs = {k: _run(eng, 64, 5, x0, 6, k) for k in ('auto', 'fused', 'phases')}
-    assert runs['auto'][0] == 'solo'
-    for k in ('fused', 'phases'):
+    runs = {k: _run(eng, 64, 5, x0, 6, k) for k in ('auto', 'solo', 'fused', 'phases')}
+    assert runs['auto'][0] == 'run' and runs['solo'][0] == 'solo'
+    for k in ('solo', 'fused', 'phases'):
         assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][2], runs[k][2])
     ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 5)
     assert relerr(runs['auto'][1], ref) < 1e-9 and relerr(runs['auto'][2], ref_lp) < 1e-9
@@ -71,12 +71,13 @@ def test_states_outside_the_interpolants_take_the_general_path():
 
 
 @pytest.mark.parametrize('nwalkers', [40, 41])
-def test_three_kernels_one_chain(nwalkers):
+def test_four_kernels_one_chain(nwalkers):
     pb, eng = _multiband()
     x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(3).standard_normal((nwalkers, 5)))
-    runs = {k: _run(eng, nwalkers, 2024, x0, 9, k) for k in ('auto', 'fused', 'phases')}
-    assert [runs[k][0] for k in ('auto', 'fused', 'phases')] == ['solo', 'fused', 'phases']
-    for k in ('fused', 'phases'):
+    runs = {k: _run(eng, nwalkers, 2024, x0, 9, k) for k in ('auto', 'solo', 'fused', 'phases')}
+    assert [runs[k][0] for k in ('auto', 'solo', 'fused', 'phases')] == ['run', 'solo', 'fused', 'phases']
+    assert runs['auto'][4].last_run_kernel() == 'run' and runs['solo'][4].last_run_kernel() == 'solo'
+    for k in ('solo', 'fused', 'phases'):
         assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][2], runs[k][2])
         assert np.array_equal(runs['auto'][3], runs[k][3])
     ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 9, 2024)
@@ -84,7 +85,7 @@ def test_three_kernels_one_chain(nwalkers):
     assert np.array_equal(runs['auto'][3], ref_acc) and 0 < ref_acc.sum() < 9 * nwalkers
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'fused', 'phases'])
+@pytest.mark.parametrize('kernel', ['auto', 'solo', 'fused', 'phases'])
 @pytest.mark.parametrize('nwalkers,randomize', [(11, True), (13, False), (27, True)])
 def test_odd_ensembles_follow_emcee_split(nwalkers, randomize, kernel):
     """An odd ensemble: the larger colour (ceil(n / 2) walkers) moves first against the smaller one, as in emcee's
@@ -99,14 +100,14 @@ def test_long_run_crosses_draw_blocks():
     """300 steps = a short first block of draw records, one full block of 256 and a remainder: nothing may change at
     the seams, for the kernel that needs no slot bookkeeping and for the ones that carry it across blocks."""
     pb, eng, x0 = _small(16, seed=8)
-    runs = {k: _run(eng, 16, 99, x0, 300, k) for k in ('auto', 'fused', 'phases')}
-    for k in ('fused', 'phases'):
+    runs = {k: _run(eng, 16, 99, x0, 300, k) for k in ('auto', 'solo', 'fused', 'phases')}
+    for k in ('solo', 'fused', 'phases'):
         assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][3], runs[k][3])
     ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 300, 99)
     assert relerr(runs['auto'][1], ref) < 1e-8 and np.array_equal(runs['auto'][3], ref_acc)
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'fused'])
+@pytest.mark.parametrize('kernel', ['auto', 'solo', 'fused'])
 def test_runs_that_continue_each_other(kernel):
     """10 + 10 + 5 steps (the second run adopts the draw records the first one left behind for it; the third changes
     the colouring, so what the second one left is discarded) == the same 25 steps of the oracle."""
@@ -340,7 +341,7 @@ def test_row_boards_companion_shape():
     nwalkers, nsteps = 40, 4
     x0 = bench.companion_walkers(nwalkers)
     ref = NativeSampler(model.engine_for(lc, priors=priors), nwalkers, 9)
-    assert ref.set_half_step_kernel('auto') == 'solo'
+    assert ref.set_half_step_kernel('auto') == 'run'
     ref.set_state(x0)
     ref.run(0, nsteps, 'random', True)
     want_chain, want_lp = ref.get_chain()
@@ -403,9 +404,9 @@ def test_light_curve_without_shared_epochs(shared_only, monkeypatch):
         monkeypatch.setenv('LCF_SHARED_EPOCHS_ONLY', '1')
     pb, eng, x0 = _small(26, seed=12)
     assert len(np.unique(pb['t'])) == len(pb['t'])
-    runs = {k: _run(eng, 26, 77, x0, 6, k) for k in ('auto', 'fused', 'phases')}
-    assert runs['auto'][0] == ('fused' if shared_only else 'solo')
-    for k in ('fused', 'phases'):
+    runs = {k: _run(eng, 26, 77, x0, 6, k) for k in ('auto', 'solo', 'fused', 'phases')}
+    assert runs['auto'][0] == ('fused' if shared_only else 'run') and runs['solo'][0] == ('fused' if shared_only else 'solo')
+    for k in ('solo', 'fused', 'phases'):
         assert np.array_equal(runs['auto'][1], runs[k][1]) and np.array_equal(runs['auto'][3], runs[k][3])
     ref, ref_lp, ref_acc = O.stretch_move_run(oracle_log_posterior(pb), x0, 6, 77)
     assert relerr(runs['auto'][1], ref) < 1e-9 and relerr(runs['auto'][2], ref_lp) < 1e-9

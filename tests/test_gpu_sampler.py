@@ -342,7 +342,7 @@ def test_long_light_curve_one_launch_and_phases():
     assert a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
     a.set_state(x0)
     a.run(0, 3, 'random', True)
-    assert a.last_run_kernel() == 'solo'
+    assert a.last_run_kernel() == 'run'
     b = NativeSampler(eng, 16, 5)
     b.set_state(x0)
     b.begin(0, 3, 'random', True)
