@@ -171,6 +171,8 @@ def init_distributed(args):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
+        # (ranks that share a device: the resident launches of two processes could keep each other's workgroups out)
+        os.environ['LCF_NO_RUN_KERNEL'] = '1'
         torch.cuda.set_device(0)
         dist.init_process_group('gloo', rank=rank, world_size=world)
     else:
@@ -407,19 +409,22 @@ def quads_per_evaluation(engine, truth):
     return float(np.sum(n) / 4.), int(np.sum(interp))
 
 
-def half_step_kernel_ms(engine, nwalkers, x0, seed, reps=1000):
-    """Average duration of the half-step kernel of a single-GPU run (one launch = one half-step = nwalkers/2 proposals:
-    proposal + thermal states + likelihood + accept test), from HIP events on the engine's stream around `reps` steps =
-    2*reps back-to-back launches (the draw-record kernels in between: 40 us per 256 steps)."""
+def half_step_kernel_ms(engine, nwalkers, x0, seed, reps=992):
+    """(average duration of ONE LAUNCH of the half-step kernel of a single-GPU run in ms, which kernel, half-steps per
+    launch), from HIP events on the engine's stream around `reps` steps of back-to-back launches (the draw-record kernels
+    in between: 30 us per 256 steps).  k_solo / k_fused: one launch = one half-step = nwalkers/2 proposals (proposal +
+    thermal states + likelihood + accept test).  k_solo_run ('run'): the workgroups stay for a block of steps -- with
+    `reps` a multiple of 32 every launch covers exactly 32 steps = 64 half-steps."""
     from lightcurve_fitting_amd.engine import NativeSampler
     s = NativeSampler(engine, nwalkers, seed)
     used = s.set_half_step_kernel('auto')
     s.set_state(x0[:nwalkers])
     s.run(0, 50, 'random', False)
     s.run(50, reps, 'random', False)
-    ms = s.last_run_ms() / (2 * reps)
+    launches = s.last_run_launches()
+    ms = s.last_run_ms() / launches
     s.close()
-    return ms, used
+    return ms, used, 2. * reps / launches
 
 
 # =====================================================================================================================
@@ -513,7 +518,8 @@ def run_mcmc(args):
     quiet_interpreter()
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(n_walkers, 5, engine, seed=SEED, collective=mode), dist,
                                      x0, args)
-    kern_ms, used = half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7) if rank == 0 or world > 1 else (None, None)
+    kern_ms, used, hs_per_launch = (half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7)
+                                    if rank == 0 or world > 1 else (None, None, None))
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)       # the chain is stored, as the reference's run does
     value = n_walkers * args.steps / elapsed
     device_ms = sampler.last_run_ms
@@ -528,15 +534,20 @@ def run_mcmc(args):
         # dominant kernel alone, at this rank's share of a half-step when the run is sharded over the GPUs
         per_rank = n_walkers // world
         quads, n_interp = quads_per_evaluation(engine, TRUTH)
-        name = {'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
+        name = {'run': 'k_solo_run<5,1,true,2,ShockCooling> (resident workgroups, one per proposal: %d half-steps per '
+                       'launch, each of them proposal + thermal states + likelihood + accept test; the rows travel from '
+                       'workgroup to workgroup through a board of tagged rows in HBM)' % round(hs_per_launch),
+                'solo': 'k_solo<5,1,true,2> (a whole half-step, one workgroup per proposal: proposal + thermal states '
                         '+ likelihood + accept test)',
                 'fused': 'k_fused<5,1,true>', 'phases': 'k_step + k_points'}[used]
-        # the committed counters are those of the default configuration (k_solo, interpolated level); any other
+        # the committed counters are those of the default configuration (k_solo_run, interpolated level); any other
         # kernel or table level has no PMC pass of its own and reports null
-        pmc_tag = 'k_solo_mcmc' if (used, args.variant) == ('solo', 3) else f'k_{used}_v{args.variant}_mcmc'
-        roof = roofline_block(name, kern_ms, per_rank // 2, quads, None, PEAK_FP64_TINSTR, ALG_INSTR,
+        pmc_tag = 'k_solo_run_mcmc' if (used, args.variant) == ('run', 3) else f'k_{used}_v{args.variant}_mcmc'
+        roof = roofline_block(name, kern_ms, round((per_rank // 2) * hs_per_launch), quads, None, PEAK_FP64_TINSTR, ALG_INSTR,
                               ALG_BYTES, pmc_tag, waves_per_launch=(per_rank // 2) * 8,
                               interp=(n_interp, N_EPOCHS) if n_interp else None)
+        roof['half_steps_per_launch'] = hs_per_launch
+        roof['kernel_ms_per_half_step'] = kern_ms / hs_per_launch
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -626,7 +637,8 @@ def run_companion(args):
     quiet_interpreter()
     sampler, probe = pick_collective(lambda mode: EnsembleSampler(nw, 8, engine, seed=SEED, collective=mode), dist, x0,
                                      args)
-    kern_ms, used = half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=200) if rank == 0 or world > 1 else (None, None)
+    kern_ms, used, hs_per_launch = (half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=192)
+                                    if rank == 0 or world > 1 else (None, None, None))
     elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = nw * args.steps / elapsed
     coll = collective_info(sampler, dist, world)
@@ -637,15 +649,21 @@ def run_companion(args):
         quads, n_interp = quads_per_evaluation(engine, COMPANION_TRUTH)
         full = int(engine.samples_per_eval)
         alg_instr = ALG_INSTR_PER_SAMPLE * full + (ALG_INSTR_PER_POINT + 20) * 8000   # + one cubic per point
-        name = {'solo': 'k_solo<8,1,true,4> (one 512-thread workgroup per proposal, its two halves take two of the four parts each)', 'fused': 'k_fused<8,1,true>',
+        name = {'run': 'k_solo_run<8,1,true,4,generic> (resident 512-thread workgroups, %d half-steps per launch; a workgroup '
+                       'takes its proposals of a half-step one after the other, its two halves two of the four parts each)'
+                       % round(hs_per_launch),
+                'solo': 'k_solo<8,1,true,4> (one 512-thread workgroup per proposal, its two halves take two of the four parts each)', 'fused': 'k_fused<8,1,true>',
                 'phases': 'k_step + k_points'}[used]
         # (the committed counters are those of the default configuration -- k_solo, interpolated level, one GPU; anything
         # else has no PMC pass of its own and reports null; on N > 1 GPUs kernel_ms is the single-GPU k_solo launch of one
         # rank's share, whichever driver runs the timed steps)
-        pmc_tag = 'k_solo_companion' if (used, args.variant, world) == ('solo', 3, 1) else f'k_{used}_v{args.variant}_companion_x{world}'
-        roof = roofline_block(name, kern_ms, per_rank // 2, quads, None, PEAK_FP64_TINSTR, alg_instr,
-                              8 * (8 + 1), pmc_tag, waves_per_launch=(per_rank // 2) * 8,
+        pmc_tag = ({'run': 'k_solo_run_companion', 'solo': 'k_solo_companion'}.get(used) if (args.variant, world) == (3, 1)
+                   else None) or f'k_{used}_v{args.variant}_companion_x{world}'
+        roof = roofline_block(name, kern_ms, round((per_rank // 2) * hs_per_launch), quads, None, PEAK_FP64_TINSTR, alg_instr,
+                              8 * (8 + 1), pmc_tag, waves_per_launch=None if used == 'run' else (per_rank // 2) * 8,
                               interp=(n_interp, 1000, 'log_lean') if n_interp else None)
+        roof['half_steps_per_launch'] = hs_per_launch
+        roof['kernel_ms_per_half_step'] = kern_ms / hs_per_launch
         if world > 1:
             roof['kernel'] += " [one rank's share as a single-GPU launch: the reference point of the multi-rank drivers]"
         out = {'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s', 'n_gpus': world,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LCF_ABI_VERSION 7
+#define LCF_ABI_VERSION 8
 
 typedef enum lcf_status {
     LCF_OK = 0,
@@ -235,6 +235,9 @@ lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int3
 enum { LCF_KERNEL_PHASES = 0, LCF_KERNEL_FUSED = 1, LCF_KERNEL_SOLO = 2, LCF_KERNEL_POPULATION = 3,
        LCF_KERNEL_POPULATION_PHASES = 4, LCF_KERNEL_RUN = 5 /* k_solo_run: a block of half-steps per launch */ };
 int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s);
+/* Launches of that kernel in the last single-GPU run (lcf_sampler_run / _run_async): two per step, or -- k_solo_run --
+ * one per block of up to 32 steps. */
+int64_t lcf_sampler_last_run_launches(const lcf_sampler* s);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
  * log-probabilities (RCCL) between phase 2 and phase 3.  All enqueue on `stream` without host sync.

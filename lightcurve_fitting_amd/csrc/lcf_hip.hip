@@ -1050,6 +1050,9 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
         keys[w] = k;
     }
     __syncthreads();
+    // Pairs [64 m, 64 m + 64) -- one wave's share of a stage (blockDim.x is a multiple of 64) -- touch keys
+    // [128 m, 128 m + 128) only while the stride is at most 64: such stages follow each other without a workgroup
+    // barrier (a wave's LDS operations execute in order); 6 of the 55 stages of 1024 keys need one on either side.
     for (int size = 2; size <= n_pad; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int i = threadIdx.x; i < (n_pad >> 1); i += blockDim.x) {
@@ -1062,9 +1065,14 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
                     keys[hi] = a;
                 }
             }
-            __syncthreads();
+            const int next = stride > 1 ? stride >> 1 : size;   // the stride of the stage that follows
+            if (stride > 64 || next > 64)
+                __syncthreads();
+            else
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
+    __syncthreads();
     for (int w = threadIdx.x; w < n_walkers; w += blockDim.x)
         perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
 }
@@ -1911,6 +1919,18 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
     ColumnOperands first_col;
 #endif
     bool first = true;
+    if (rel0 == 0) {
+        // The run's first launch: the state in front of it is version g_run0 of every row (what a draw record's age
+        // points at until the walker has moved in this run).  Whoever needs a row polls for it: no barrier behind this.
+        const int nd = ND > 0 ? ND : sm.n_dim;
+        const int col = threadIdx.x & 31;   // (n_dim + 2 <= kMaxDim + 2 columns)
+        for (int w = blockIdx.x * (int)(blockDim.x / 32) + (int)(threadIdx.x / 32); w < sm.n_walkers;
+             w += gridDim.x * (blockDim.x / 32))
+            if (col <= nd + 1) {
+                const double v = col < nd ? sm.X[(size_t)w * nd + col] : col == nd ? sm.LP[w] : (double)sm.nacc[w];
+                board_post<LCF_RUN_AGENT != 0>(sm.board, sm, (unsigned int)g_run0, w, col, v);
+            }
+    }
 #pragma unroll 1
     for (int h = 0; h < n_hs; ++h) {
         const DrawRec* draws = draws0 + (size_t)h * sm.n_half;
@@ -2941,6 +2961,7 @@ struct lcf_sampler {
     bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
     int half_step_kernel = LCF_HALF_STEP_AUTO;
     int last_kernel = -1;     // what the last run's half-steps were (lcf_sampler_last_run_kernel)
+    long long last_launches = 0;   // launches of that kernel in the last run (lcf_sampler_last_run_launches)
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
     void* board_mem = nullptr;               // this rank's row board (uncached device memory), see DevSampler
     std::vector<void*> board_opened;         // peers' boards mapped through IPC
@@ -3313,9 +3334,16 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 // all be resident at once: the grid is what the device holds (occupancy x CUs; each workgroup then takes several slots
 // of a half-step), and a process keeps ONE such launch in flight per device (`g_run_busy`): a second sampler's run
 // enqueued meanwhile on another stream takes a launch per half-step.
+// ... and whose proposals all have a workgroup of their own (n_half <= kRunSlots: 2 workgroups of 512 threads per CU of
+// an MI355X): with several proposals per workgroup and half-step the fixed share of each workgroup loses against the
+// hardware's dispatch of one workgroup per proposal -- proposals that the prior excludes cost nothing there -- (configs[2],
+// 2048 proposals: 80.7 against 76.9 us per half-step), and the boundary it saves is 2 % of such a launch.
+constexpr int kRunSlots = 512;
 bool run_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
-    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0;
+    static const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;   // (tests: several slots per workgroup)
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
+           (s->ds.n_half <= kRunSlots || any_size);
 }
 
 struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; };
@@ -3649,6 +3677,9 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     if (lcf_status st = logprob_dev(e, ds.n_walkers, ds.X, ds.LP, e->stream, 1)) return st;
     LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
+    if (s->run_board_mem)   // (the abort word and its diagnosis behind the rows of the one-launch runs' board)
+        LCF_HIP(hipMemsetAsync(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int), 0,
+                               5 * sizeof(unsigned int), e->stream));
     LCF_HIP(hipStreamSynchronize(e->stream));
     s->has_state = true;
     return LCF_OK;
@@ -3718,6 +3749,8 @@ lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int3
 }
 
 int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s) { return s ? s->last_kernel : -1; }
+
+int64_t lcf_sampler_last_run_launches(const lcf_sampler* s) { return s ? s->last_launches : 0; }
 
 int32_t lcf_sampler_one_launch(const lcf_sampler* s) { return s && (solo_eligible(s) || fused_eligible(s)) ? 1 : 0; }
 
@@ -4144,14 +4177,9 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
             LCF_HIP(hipMemsetAsync(s->run_board_mem, 0, s->run_board_bytes(), st));   // tag 0: no version
         }
         s->last_kernel = LCF_KERNEL_RUN;
-        DevSampler rs = s->ds;
-        rs.board = static_cast<unsigned long long*>(s->run_board_mem);
-        rs.ring = kRunRing;
-        const long long cells = (long long)rs.n_walkers * (rs.n_dim + 2);
-        hipLaunchKernelGGL(k_board_init, dim3((unsigned)((std::max<long long>(cells, 5) + 255) / 256)), dim3(256), 0, st, rs,
-                           (unsigned int)s->g_run0);
-        LCF_HIP(hipGetLastError());
-        for (long long rel = 0; rel < 2 * n_steps;) {
+        s->last_launches = 0;
+        for (long long rel = 0; rel < 2 * n_steps;) {   // (the first launch posts the start state on the board itself)
+            ++s->last_launches;
             if (lcf_status r = enter_half_step(s, rel, st)) return r;
             const int64_t b = s->blk_current;
             const long long end = 2 * (s->block_start(b) + s->block_len(b));
@@ -4170,6 +4198,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     // [commit previous + draw + thermal states] -> [per-point likelihood]; one trailing commit
     const bool fused = fused_eligible(s);
     s->last_kernel = solo_eligible(s) ? LCF_KERNEL_SOLO : fused ? LCF_KERNEL_FUSED : LCF_KERNEL_PHASES;
+    s->last_launches = 2 * n_steps;
     if (solo_eligible(s)) {  // one workgroup per proposal, nothing pending between launches
         for (int64_t k = 0; k < 2 * n_steps; ++k)
             if (lcf_status r = launch_solo(s, k, st)) return r;

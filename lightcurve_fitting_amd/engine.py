@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LCF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblcf_hip.so')
 
-LCF_ABI_VERSION = 7
+LCF_ABI_VERSION = 8
 N_CONSTS = 12
 
 MODEL_SHOCK_COOLING = 1
@@ -104,6 +104,7 @@ SIGNATURES = [
     ('lcf_sampler_one_launch', C.c_int32, [C.c_void_p]),
     ('lcf_sampler_set_half_step_kernel', C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     ('lcf_sampler_last_run_kernel', C.c_int32, [C.c_void_p]),
+    ('lcf_sampler_last_run_launches', C.c_int64, [C.c_void_p]),
     ('lcf_sampler_half_step_rows', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ('lcf_sampler_rows_ptr', C.c_void_p, [C.c_void_p, C.POINTER(C.c_int32)]),
     ('lcf_sampler_check', C.c_int, [C.c_void_p]),
@@ -459,6 +460,10 @@ class NativeSampler:
         a population) | 'population-phases' (None: no run yet)."""
         return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run'}.get(
             self._lib.lcf_sampler_last_run_kernel(self._h))
+
+    def last_run_launches(self):
+        """Launches of the half-step kernel in the last single-GPU run (two per step; 'run': one per block of steps)."""
+        return int(self._lib.lcf_sampler_last_run_launches(self._h))
 
     def set_half_step_kernel(self, choice='auto'):
         """Restrict the kernels a single-GPU run uses for a half-step ('auto' | 'solo' | 'fused' | 'phases'; same

@@ -85,6 +85,26 @@ def test_four_kernels_one_chain(nwalkers):
     assert np.array_equal(runs['auto'][3], ref_acc) and 0 < ref_acc.sum() < 9 * nwalkers
 
 
+def test_resident_workgroups_with_several_slots_each(monkeypatch):
+    """k_solo_run with fewer workgroups than a half-step has proposals (LCF_RUN_GRID: as on a device that holds fewer
+    than the ensemble needs): every workgroup takes its slots of a half-step one after the other, still waits only for
+    rows of earlier half-steps, and the chain is the one of a launch per half-step -- over several launches (45 steps =
+    a block of 32 and one of 13) and with the state, the counts and a continued run read back."""
+    monkeypatch.setenv('LCF_RUN_GRID', '7')
+    pb, eng = _multiband()
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(4).standard_normal((41, 5)))
+    ref = _run(eng, 41, 31, x0, 45, 'solo')
+    got = _run(eng, 41, 31, x0, 45, 'auto')
+    assert got[0] == 'run' and got[4].last_run_kernel() == 'run' and got[4].last_run_launches() == 2
+    assert ref[4].last_run_launches() == 90
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    for a, b in zip(got[4].get_state(), ref[4].get_state()):
+        assert np.array_equal(a, b)
+    for s in (got[4], ref[4]):
+        s.run(45, 5, 'random', True)
+    assert np.array_equal(got[4].get_chain()[0], ref[4].get_chain()[0]) and np.array_equal(got[4].naccepted(), ref[4].naccepted())
+
+
 @pytest.mark.parametrize('kernel', ['auto', 'solo', 'fused', 'phases'])
 @pytest.mark.parametrize('nwalkers,randomize', [(11, True), (13, False), (27, True)])
 def test_odd_ensembles_follow_emcee_split(nwalkers, randomize, kernel):

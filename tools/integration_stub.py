@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 _dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
-LCF_ABI_VERSION, LCF_MODEL_SHOCK_COOLING = 7, 1
+LCF_ABI_VERSION, LCF_MODEL_SHOCK_COOLING = 8, 1
 c1, c2 = 0.0479924307336622, 281739904251.4432           # models.py:1101-1102
 
 

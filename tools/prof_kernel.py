@@ -26,16 +26,16 @@ def main():
         s = NativeSampler(eng, bench.WALKERS_PER_GPU, bench.SEED + 7)
         s.set_state(bench.initial_walkers(bench.WALKERS_PER_GPU))
         s.run(0, steps, 'random', False)
-        print(json.dumps({'workload': workload, 'kernel': s.set_half_step_kernel('auto'),
-                          'kernel_ms': s.last_run_ms() / (2 * steps)}))
+        print(json.dumps({'workload': workload, 'kernel': s.set_half_step_kernel('auto'), 'launches': s.last_run_launches(),
+                          'kernel_ms': s.last_run_ms() / s.last_run_launches()}))
     elif workload == 'companion':
         model, lc, priors, _ = bench.build_companion(0)
         eng = model.engine_for(lc, priors=priors)
         s = NativeSampler(eng, bench.COMPANION_WALKERS, bench.SEED + 7)
         s.set_state(bench.companion_walkers(bench.COMPANION_WALKERS))
         s.run(0, steps, 'random', False)
-        print(json.dumps({'workload': workload, 'kernel': s.set_half_step_kernel('auto'),
-                          'kernel_ms': s.last_run_ms() / (2 * steps)}))
+        print(json.dumps({'workload': workload, 'kernel': s.set_half_step_kernel('auto'), 'launches': s.last_run_launches(),
+                          'kernel_ms': s.last_run_ms() / s.last_run_launches()}))
     elif workload == 'population':
         args = bench.parse_args(['--workload', 'population', '--steps', str(steps), '--warmup', '2', '--no-cpu-baseline'])
         bench.run_population(args)
