@@ -981,6 +981,12 @@ struct DevSampler {
     unsigned long long* peer_board[kMaxPeers];
     int n_board_ranks, board_rank;
     int ring, run_mode;   // versions a board keeps (a power of two); 1: the board of a one-launch run (k_solo_run), no peers
+    // One-launch runs write the snapshot the host reads after a run -- [error word | X | LP | n_accepted] in pinned host
+    // memory -- themselves, with the state, in their last step; a workgroup that meets a NaN or gives up a wait says so in
+    // a word of its own behind it (snap_flags[blockIdx.x & (kSnapFlags - 1)] = 1 / snap_flags[kSnapFlags + ...] = 2;
+    // plain stores, cleared with the state only: errors stay until set_state).  Null: the snapshot kernel does it.
+    unsigned long long* snap_out;
+    unsigned int* snap_flags;
     // Bound of every wait for another rank (mailbox entries, board rows, progress words), in ticks of the 100 MHz wall
     // clock: peer_wait_ticks().  A rank's stream holds only a few ms of launches, so a host that stalls longer than
     // this on ONE rank ends the run on ALL of them -- the default is therefore seconds, not the 0.5 s of round 2.
@@ -1415,6 +1421,7 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
 // NEXT launch: stream order proves that the launch before it is complete): half-steps G - 1 and G are the only ones in
 // flight anywhere, they read versions >= G - 3 and write G and G + 1, so eight versions are never overrun.
 constexpr int kRing = 8;
+constexpr int kSnapFlags = 1024;
 // One-launch runs (k_solo_run): a launch covers at most kRunSpan half-steps, reads versions >= G - 3 and writes G + 1:
 // kRunRing versions are never overrun however far the workgroups of a launch drift apart.
 constexpr int kRunRing = 128;
@@ -1461,6 +1468,7 @@ __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsi
         __hip_atomic_store(flag + 4, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     atomicOr(sm.err, 2);
+    if (sm.snap_flags) sm.snap_flags[kSnapFlags + (blockIdx.x & (kSnapFlags - 1))] = 2u;
 }
 // The number with tag `tag` from this rank's board, once it is there (bounded wait: DevSampler::wait_ticks, then the launch is aborted
 // and the run ends with an error; NaN after an abort).
@@ -1659,14 +1667,10 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // here; `first`: the workgroup's first half-step of the launch (tables staged, first columns fetched: both stay).
 // Returns true when the run is aborted (uniform over the workgroup).
 template <int ND, int VARIANT, bool THERM, int NPARTS, int BOARD, int MODEL>
-__device__ __forceinline__ bool solo_half_step(const DevProblem* __restrict__ pbp, const DevSampler& sm, long long row,
+__device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevProblem* __restrict__ pbp, const DevSampler& sm, long long row,
                                                const DrawRec* __restrict__ draws, const DrawRec* draws_next, long long G,
                                                long long g_run0, int i, unsigned char* smem, ColumnOperands& first_col,
                                                bool first, bool write_state, const int tid) {
-    // The problem is read through a constant-address-space pointer: scalar loads where a field is used, instead of
-    // 700 bytes of kernel arguments preloaded into (and spilled from) scalar registers.
-    typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
-    const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;                                     // 4 wave sums per part (32 reserved)
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
@@ -1848,13 +1852,22 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem* __restrict__ pb
                     sm.LP[dr.wid] = v;
                 else
                     sm.nacc[dr.wid] = (long long)v;
+                if (BOARD == 2 && sm.snap_out) {   // ... and the host's copy of it
+                    const size_t nw = sm.n_walkers;
+                    if (tid < nd) sm.snap_out[1 + (size_t)dr.wid * nd + tid] = (unsigned long long)__double_as_longlong(v);
+                    else if (tid == nd) sm.snap_out[1 + nw * nd + dr.wid] = (unsigned long long)__double_as_longlong(v);
+                    else sm.snap_out[1 + nw * nd + nw + dr.wid] = (unsigned long long)(long long)v;
+                }
             }
             if (BOARD == 2 && sm.store_chain) {   // (one GPU: every walker's row is decided here)
                 if (tid < nd) sm.chain[((size_t)row * sm.n_walkers + dr.wid) * nd + tid] = v;
                 else if (tid == nd) sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = v;
             }
         }
-        if (tid == 0 && nlp != nlp) atomicOr(sm.err, 1);
+        if (tid == 0 && nlp != nlp) {
+            atomicOr(sm.err, 1);
+            if (BOARD == 2 && sm.snap_flags) sm.snap_flags[blockIdx.x & (kSnapFlags - 1)] = 1u;
+        }
         LCF_STAMP(0, 10);
         return false;
     }
@@ -1896,7 +1909,11 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
             const DrawRec* draws_next, long long G, long long g_run0, int slot_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     ColumnOperands first_col;
-    solo_half_step<ND, VARIANT, THERM, NPARTS, BOARD ? 1 : 0, MODEL>(pbp, sm, row, draws, draws_next, G, g_run0,
+    // The problem is read through a constant-address-space pointer: scalar loads where a field is used, instead of
+    // 700 bytes of kernel arguments preloaded into (and spilled from) scalar registers.
+    typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
+    const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
+    solo_half_step<ND, VARIANT, THERM, NPARTS, BOARD ? 1 : 0, MODEL>(pb, pbp, sm, row, draws, draws_next, G, g_run0,
                                                                      blockIdx.x + (BOARD ? slot_lo : 0), smem, first_col, true,
                                                                      true, threadIdx.x);
 }
@@ -1918,6 +1935,8 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
 #if LCF_RUN_KEEP_COLS
     ColumnOperands first_col;
 #endif
+    typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
+    const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     bool first = true;
     if (rel0 == 0) {
         // The run's first launch: the state in front of it is version g_run0 of every row (what a draw record's age
@@ -1944,7 +1963,7 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
             const bool more = i + (int)gridDim.x < sm.n_half;
             const DrawRec* hint = more ? draws + gridDim.x : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
             const int tid = threadIdx.x;
-            if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pbp, sm, (rel0 + h) >> 1, draws, hint,
+            if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pb, pbp, sm, (rel0 + h) >> 1, draws, hint,
                                                                      g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
                                                                      rel0 + h >= state_from, tid))
                 return;
@@ -2985,6 +3004,8 @@ struct lcf_sampler {
     size_t snap_lp() const { return snap_x() + (size_t)ds.n_walkers * ds.n_dim * sizeof(double); }
     size_t snap_acc() const { return snap_lp() + (size_t)ds.n_walkers * sizeof(double); }
     size_t snap_bytes() const { return snap_acc() + (size_t)ds.n_walkers * sizeof(long long); }
+    size_t snap_alloc() const { return snap_bytes() + 2 * kSnapFlags * sizeof(unsigned int); }   // + the workgroups' error words
+    unsigned int* snap_flags() const { return reinterpret_cast<unsigned int*>(snap + snap_bytes()); }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_snap = nullptr;   // behind the snapshot kernel: what a caller of a finished run waits for
     double last_ms = 0.;
@@ -3388,6 +3409,8 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
     rs.board_rank = 0;
     rs.ring = kRunRing;
     rs.run_mode = 1;
+    rs.snap_out = reinterpret_cast<unsigned long long*>(s->snap);
+    rs.snap_flags = s->snap_flags();
     const DrawRec* draws = s->rows(rel);
     const size_t lds = solo_lds_bytes(e);
     const long long g_run0 = s->g_run0;
@@ -3648,7 +3671,8 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     LCF_HIP(hipEventCreate(&s->ev0));
     LCF_HIP(hipEventCreate(&s->ev1));
     LCF_HIP(hipEventCreateWithFlags(&s->ev_snap, hipEventDisableTiming));
-    LCF_HIP(hipHostMalloc((void**)&s->snap, s->snap_bytes(), hipHostMallocDefault));
+    LCF_HIP(hipHostMalloc((void**)&s->snap, s->snap_alloc(), hipHostMallocDefault));
+    std::memset(s->snap, 0, s->snap_alloc());
     *out = s;
     return LCF_OK;
 }
@@ -3677,6 +3701,7 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     if (lcf_status st = logprob_dev(e, ds.n_walkers, ds.X, ds.LP, e->stream, 1)) return st;
     LCF_HIP(hipMemsetAsync(ds.nacc, 0, (size_t)ds.n_walkers * sizeof(long long), e->stream));
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
+    std::memset(s->snap_flags(), 0, 2 * kSnapFlags * sizeof(unsigned int));   // (after the device synchronisation above)
     if (s->run_board_mem)   // (the abort word and its diagnosis behind the rows of the one-launch runs' board)
         LCF_HIP(hipMemsetAsync(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int), 0,
                                5 * sizeof(unsigned int), e->stream));
@@ -3777,6 +3802,12 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
     if (lcf_status st = settle(s)) return st;
     int err = 0;
     std::memcpy(&err, s->snap, sizeof(int));
+    {   // (what the workgroups of one-launch runs reported themselves)
+        const unsigned int* flags = s->snap_flags();
+        unsigned int any = 0;
+        for (int k = 0; k < 2 * kSnapFlags; ++k) any |= flags[k];
+        err |= (int)any;
+    }
     if (err & 2) {
         // (an aborted multi-rank run leaves the ranks with different states -- a rank has committed its own walkers of
         // the half-step the others gave up on: the ensemble must be set again, on every rank, before the next run)
@@ -4191,7 +4222,10 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
         s->g_next += 2 * n_steps;
         LCF_HIP(hipEventRecord(s->ev1, st));
         run_release(s->e->device, st);
-        if (lcf_status r = enqueue_snapshot(s)) return r;
+        // (the last step wrote the snapshot with the state: no snapshot kernel; the caller waits for this event)
+        LCF_HIP(hipEventRecord(s->ev_snap, st));
+        s->snap_enqueued = true;
+        s->snap_valid = false;
         return speculate_continuation(s, st);
     }
     // per half-step: ONE launch (k_fused) when everything a workgroup needs fits in LDS, else

@@ -15,9 +15,9 @@ mkdir -p $OUT $FINAL
 cd /tmp && export TMPDIR=/tmp
 FAILED=0
 declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
-declare -A PSTEPS=( [mcmc]=5 [companion]=2 [population]=3 [sed]=1 )
-declare -A KERNEL=( [mcmc]=k_solo [companion]=k_solo [population]=k_pop [sed]=k_sed_interp )
-declare -A PTAG=( [mcmc]=k_solo_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
+declare -A PSTEPS=( [mcmc]=64 [companion]=2 [population]=3 [sed]=1 )   # (mcmc: two launches of 64 half-steps)
+declare -A KERNEL=( [mcmc]=k_solo_run [companion]=k_solo [population]=k_pop [sed]=k_sed_interp )
+declare -A PTAG=( [mcmc]=k_solo_run_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
 for W in mcmc companion population sed; do
   echo "== $W: kernel trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 $R/bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/trace_$W.log \

@@ -29,6 +29,9 @@ for n, v in zip(names, np.median(d, axis=0)):
     print(f'{n:45s} {v:9.0f}')
 tot = a[:, 10] - a[:, 0]
 print('total: median', np.median(tot), ' min', tot.min(), ' p90', np.percentile(tot, 90), ' max', tot.max())
+print('per phase min:', ' '.join(f'{v:.0f}' for v in d.min(axis=0)))
+print('per phase p10:', ' '.join(f'{v:.0f}' for v in np.percentile(d, 10, axis=0)))
+print('per phase mean:', ' '.join(f'{v:.0f}' for v in d.mean(axis=0)))
 print('per phase p90:', ' '.join(f'{v:.0f}' for v in np.percentile(d, 90, axis=0)))
 print('per phase max:', ' '.join(f'{v:.0f}' for v in d.max(axis=0)))
 print('wave 1: staging done at', np.median(a[:, 11] - a[:, 0]), ' columns done at', np.median(a[:, 12] - a[:, 0]),
