@@ -987,6 +987,11 @@ struct DevSampler {
     // plain stores, cleared with the state only: errors stay until set_state).  Null: the snapshot kernel does it.
     unsigned long long* snap_out;
     unsigned int* snap_flags;
+    // ... and write the state into a second set of buffers (the host then swaps the two sets): a launch that gives up
+    // leaves the state it started from untouched, and the host runs the same steps again, a launch per half-step.
+    double* X_out;
+    double* LP_out;
+    long long* nacc_out;
     // Bound of every wait for another rank (mailbox entries, board rows, progress words), in ticks of the 100 MHz wall
     // clock: peer_wait_ticks().  A rank's stream holds only a few ms of launches, so a host that stalls longer than
     // this on ONE rank ends the run on ALL of them -- the default is therefore seconds, not the 0.5 s of round 2.
@@ -1087,8 +1092,9 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
 // ([1 + 2 n_steps][n_walkers]): row 0 = the half-step in front of the block (copied from the previous block, or all
 // -1 at the start of a run), row 1 + 2 k + half = half-step (k, half) of the block.
 __global__ void k_slots(int n_walkers, int n_half, const int* __restrict__ perm, long long n_steps,
-                        int* __restrict__ slot_of) {
+                        int* __restrict__ slot_of, const int* __restrict__ front) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n_walkers) slot_of[idx] = front ? front[idx] : -1;   // row 0 (nobody in this launch reads it)
     if (idx >= n_steps * n_walkers) return;
     const long long row = idx / n_walkers;
     const int pos = (int)(idx % n_walkers);  // position in the permutation: colour 0 = first n_half entries
@@ -1846,12 +1852,15 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             // (a one-launch run writes the state in its last step only: every walker moves exactly once there, while two
             // moves of a walker in one launch come from different workgroups, and whose store reaches memory last is open)
             if (BOARD != 2 || write_state) {
+                double* X = BOARD == 2 ? sm.X_out : sm.X;
+                double* LP = BOARD == 2 ? sm.LP_out : sm.LP;
+                long long* nacc = BOARD == 2 ? sm.nacc_out : sm.nacc;
                 if (tid < nd)
-                    sm.X[(size_t)dr.wid * nd + tid] = v;
+                    X[(size_t)dr.wid * nd + tid] = v;
                 else if (tid == nd)
-                    sm.LP[dr.wid] = v;
+                    LP[dr.wid] = v;
                 else
-                    sm.nacc[dr.wid] = (long long)v;
+                    nacc[dr.wid] = (long long)v;
                 if (BOARD == 2 && sm.snap_out) {   // ... and the host's copy of it
                     const size_t nw = sm.n_walkers;
                     if (tid < nd) sm.snap_out[1 + (size_t)dr.wid * nd + tid] = (unsigned long long)__double_as_longlong(v);
@@ -1930,7 +1939,8 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
 template <int ND, int VARIANT, bool THERM, int NPARTS, int MODEL>
 __global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
 void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long long rel0, const DrawRec* __restrict__ draws0,
-                long long g_run0, int n_hs, long long state_from) {
+                long long g_run0, int n_hs, long long state_from, int n_wg) {
+    // (n_wg = gridDim.x, except in the test of a launch whose workgroups are not all there: LCF_RUN_TEST_MISSING)
     extern __shared__ __align__(16) unsigned char smem[];
 #if LCF_RUN_KEEP_COLS
     ColumnOperands first_col;
@@ -1944,7 +1954,7 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
         const int nd = ND > 0 ? ND : sm.n_dim;
         const int col = threadIdx.x & 31;   // (n_dim + 2 <= kMaxDim + 2 columns)
         for (int w = blockIdx.x * (int)(blockDim.x / 32) + (int)(threadIdx.x / 32); w < sm.n_walkers;
-             w += gridDim.x * (blockDim.x / 32))
+             w += n_wg * (int)(blockDim.x / 32))
             if (col <= nd + 1) {
                 const double v = col < nd ? sm.X[(size_t)w * nd + col] : col == nd ? sm.LP[w] : (double)sm.nacc[w];
                 board_post<LCF_RUN_AGENT != 0>(sm.board, sm, (unsigned int)g_run0, w, col, v);
@@ -1954,14 +1964,14 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
     for (int h = 0; h < n_hs; ++h) {
         const DrawRec* draws = draws0 + (size_t)h * sm.n_half;
 #pragma unroll 1
-        for (int i = blockIdx.x; i < sm.n_half; i += gridDim.x) {
+        for (int i = blockIdx.x; i < sm.n_half; i += n_wg) {
             if (draws[i].wid < 0) continue;   // (uniform) an odd ensemble's smaller colour leaves its last slot empty
 #if !LCF_RUN_KEEP_COLS
             ColumnOperands first_col;         // (re-fetched per half-step, from L2: 26 registers that need not live on)
 #endif
             // the record this workgroup needs next: its next slot of this half-step, else its first of the next one
-            const bool more = i + (int)gridDim.x < sm.n_half;
-            const DrawRec* hint = more ? draws + gridDim.x : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
+            const bool more = i + n_wg < sm.n_half;
+            const DrawRec* hint = more ? draws + n_wg : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
             const int tid = threadIdx.x;
             if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pb, pbp, sm, (rel0 + h) >> 1, draws, hint,
                                                                      g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
@@ -2984,6 +2994,14 @@ struct lcf_sampler {
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
     void* board_mem = nullptr;               // this rank's row board (uncached device memory), see DevSampler
     std::vector<void*> board_opened;         // peers' boards mapped through IPC
+    // One-launch runs write their final state into the other of two sets of state buffers (DevSampler::X_out ...):
+    // ds.X / LP / nacc name the set that holds the state behind everything enqueued so far.
+    double* alt_X = nullptr;
+    double* alt_LP = nullptr;
+    long long* alt_nacc = nullptr;
+    bool run_off = false;                    // a one-launch run of this sampler gave up once: launches per half-step from then on
+    int replay_split = 0, replay_store = 0;  // the last one-launch run, should it have to be repeated
+    int64_t replay_first = 0, replay_steps = -1;
     void* run_board_mem = nullptr;           // the board of one-launch runs (k_solo_run): kRunRing versions, this GPU only
     int run_capacity = -1;                   // workgroups of k_solo_run the device holds at once (-1: not asked yet)
     size_t run_board_bytes() const {
@@ -3075,13 +3093,8 @@ lcf_status generate_steps(lcf_sampler* s, int buf, int64_t step0, int64_t len, i
     int* slots = nullptr;
     if (need_slots) {
         slots = s->d_slot[buf];
-        const size_t row = (size_t)ds.n_walkers * sizeof(int);
-        if (!front)
-            LCF_HIP(hipMemsetAsync(slots, 0xff, row, gs));
-        else
-            LCF_HIP(hipMemcpyAsync(slots, front, row, hipMemcpyDeviceToDevice, gs));
         hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gs, ds.n_walkers, ds.n_half, perm,
-                           (long long)len, slots);
+                           (long long)len, slots, front);
     }
     const long long recs = (long long)len * 2 * ds.n_half;
     hipLaunchKernelGGL(k_draws, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, gs, ds, perm, slots,
@@ -3355,16 +3368,18 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 // all be resident at once: the grid is what the device holds (occupancy x CUs; each workgroup then takes several slots
 // of a half-step), and a process keeps ONE such launch in flight per device (`g_run_busy`): a second sampler's run
 // enqueued meanwhile on another stream takes a launch per half-step.
-// ... and whose proposals all have a workgroup of their own (n_half <= kRunSlots: 2 workgroups of 512 threads per CU of
-// an MI355X): with several proposals per workgroup and half-step the fixed share of each workgroup loses against the
-// hardware's dispatch of one workgroup per proposal -- proposals that the prior excludes cost nothing there -- (configs[2],
-// 2048 proposals: 80.7 against 76.9 us per half-step), and the boundary it saves is 2 % of such a launch.
+// ... and whose proposals have a workgroup of their own (n_half <= kRunSlots: 2 workgroups of 512 threads per CU of an
+// MI355X) or, for light curves of at most two parts, share one with up to three others.  With several proposals per
+// workgroup and half-step the fixed share of each workgroup competes with the hardware's dispatch of one workgroup per
+// proposal, where a proposal that the prior excludes costs nothing: measured per half-step, k_solo_run against k_solo,
+// configs[1]'s light curve with 512 / 1024 / 2048 / 4096 walkers 4.9 / 6.0 / 11.8 / 22.7 against 6.1 / 7.8 / 13.5 /
+// 23.6 us; configs[2] (four parts, 2048 proposals) 80.7 against 76.9 us -- the boundary it saves is 2 % of that launch.
 constexpr int kRunSlots = 512;
 bool run_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
     static const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;   // (tests: several slots per workgroup)
-    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
-           (s->ds.n_half <= kRunSlots || any_size);
+    return !disabled && !s->run_off && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
+           (s->ds.n_half <= kRunSlots || (s->e->dp.n_parts <= 2 && s->ds.n_half <= 4 * kRunSlots) || any_size);
 }
 
 struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; };
@@ -3411,18 +3426,24 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
     rs.run_mode = 1;
     rs.snap_out = reinterpret_cast<unsigned long long*>(s->snap);
     rs.snap_flags = s->snap_flags();
+    rs.X_out = s->alt_X;
+    rs.LP_out = s->alt_LP;
+    rs.nacc_out = s->alt_nacc;
     const DrawRec* draws = s->rows(rel);
     const size_t lds = solo_lds_bytes(e);
     const long long g_run0 = s->g_run0;
     const long long state_from = 2 * (s->run_steps - 1);   // X / LP / counts: written by the run's last step
+    // (test of the recovery from a launch whose workgroups are not all resident: the last one is not launched at all)
+    const bool test_missing = std::getenv("LCF_RUN_TEST_MISSING") != nullptr;
     const int spec = specialised_model(e->dp);
 #define LCF_RUN5(ND, NP, M)                                                                                           \
     do {                                                                                                              \
         if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M>, kBlock * 2, lds)) return r;                \
         if (s->run_capacity < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");              \
-        const dim3 grid((unsigned)std::min(s->ds.n_half, s->run_capacity));                                           \
+        const int n_wg = std::min(s->ds.n_half, s->run_capacity);                                                     \
+        const dim3 grid((unsigned)(test_missing && n_wg > 1 ? n_wg - 1 : n_wg));                                      \
         hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
-                           g_run0, n_hs, state_from);                                                                 \
+                           g_run0, n_hs, state_from, n_wg);                                                           \
     } while (0)
 #define LCF_RUN4(ND, NP)                                                                                              \
     do {                                                                                                              \
@@ -3820,6 +3841,38 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
         else if (s->board_mem)
             hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - 5 * sizeof(unsigned int), sizeof w,
                       hipMemcpyDeviceToHost);
+        if (run && s->replay_steps >= 0 && s->replay_split != LCF_SPLIT_HOST) {
+            // The launch's workgroups were not all resident (somebody else's resident kernel on this GPU): it gave up
+            // within the bound of its waits and has written no state -- that goes into the other set of buffers, in the
+            // last step.  Take the state it started from, drop what it reported, and run the same steps again with a
+            // launch per half-step (as every later run of this sampler).
+            LCF_HIP(hipStreamSynchronize(s->e->stream));
+            std::swap(s->ds.X, s->alt_X);
+            std::swap(s->ds.LP, s->alt_LP);
+            std::swap(s->ds.nacc, s->alt_nacc);
+            int sticky = 0;
+            std::memcpy(&sticky, s->snap, sizeof(int));
+            sticky &= 1;                                   // (a NaN of an earlier run stays reported)
+            LCF_HIP(hipMemcpy(s->ds.err, &sticky, sizeof(int), hipMemcpyHostToDevice));
+            std::memcpy(s->snap, &sticky, sizeof(int));
+            std::memset(s->snap_flags(), 0, 2 * kSnapFlags * sizeof(unsigned int));
+            LCF_HIP(hipMemset(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int), 0,
+                              5 * sizeof(unsigned int)));
+            static bool told = false;
+            if (!told)
+                std::fprintf(stderr, "liblcf_hip: a one-launch run waited %.1f s for version %u of walker %u: its workgroups were "
+                             "not all resident (another resident kernel on this GPU?); the steps are repeated with a launch per "
+                             "half-step, as are this sampler's later runs (LCF_NO_RUN_KERNEL=1 avoids the wait)\n",
+                             sec, w[2], w[3]);
+            told = true;
+            s->run_off = true;
+            s->spec_first = -1;
+            invalidate_snapshot(s);
+            const int64_t n = s->replay_steps;
+            s->replay_steps = -1;
+            if (lcf_status st = lcf_sampler_run_async(s, s->replay_first, n, s->replay_split, nullptr, s->replay_store)) return st;
+            return lcf_sampler_check(s);
+        }
         if (run) {
             char msg[260];
             std::snprintf(msg, sizeof msg, "one-launch run: version %u of walker %u (column %u) was not posted within %.1f s: "
@@ -4201,12 +4254,17 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     LCF_HIP(hipEventRecord(s->ev0, st));
     if (one_launch) {   // the workgroups stay for a block of half-steps and hand each other rows (k_solo_run)
         if (!s->run_board_mem) {
-            if (std::getenv("LCF_RUN_BOARD_UNCACHED"))   // (experiment)
-                LCF_HIP(hipExtMallocWithFlags(&s->run_board_mem, s->run_board_bytes(), hipDeviceMallocUncached));
-            else
-                LCF_HIP(hipMalloc(&s->run_board_mem, s->run_board_bytes()));
+            LCF_HIP(hipMalloc(&s->run_board_mem, s->run_board_bytes()));
             LCF_HIP(hipMemsetAsync(s->run_board_mem, 0, s->run_board_bytes(), st));   // tag 0: no version
+            const size_t nw = s->ds.n_walkers;
+            if (lcf_status r = dalloc(&s->alt_X, nw * s->ds.n_dim, s->owned)) return r;
+            if (lcf_status r = dalloc(&s->alt_LP, nw, s->owned)) return r;
+            if (lcf_status r = dalloc(&s->alt_nacc, nw, s->owned)) return r;
         }
+        s->replay_first = first_step;
+        s->replay_steps = n_steps;
+        s->replay_split = split_mode;
+        s->replay_store = store_chain;
         s->last_kernel = LCF_KERNEL_RUN;
         s->last_launches = 0;
         for (long long rel = 0; rel < 2 * n_steps;) {   // (the first launch posts the start state on the board itself)
@@ -4220,6 +4278,9 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
             rel += n;
         }
         s->g_next += 2 * n_steps;
+        std::swap(s->ds.X, s->alt_X);          // the state behind this run is in the other set now
+        std::swap(s->ds.LP, s->alt_LP);
+        std::swap(s->ds.nacc, s->alt_nacc);
         LCF_HIP(hipEventRecord(s->ev1, st));
         run_release(s->e->device, st);
         // (the last step wrote the snapshot with the state: no snapshot kernel; the caller waits for this event)

@@ -105,6 +105,30 @@ def test_resident_workgroups_with_several_slots_each(monkeypatch):
     assert np.array_equal(got[4].get_chain()[0], ref[4].get_chain()[0]) and np.array_equal(got[4].naccepted(), ref[4].naccepted())
 
 
+def test_a_resident_launch_that_cannot_finish_is_repeated_launch_by_launch(monkeypatch, capfd):
+    """k_solo_run's workgroups wait for each other, so all of them must be on the device at once.  When they are not
+    (LCF_RUN_TEST_MISSING: the last workgroup is never launched -- as when another process's resident kernel holds the
+    compute units), the waits end after LCF_PEER_WAIT_S, the launch has not touched the state it started from, and the
+    library repeats the same steps with a launch per half-step: same chain, same counts, one line on stderr, and the
+    sampler stays with k_solo afterwards."""
+    pb, eng = _multiband()
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(6).standard_normal((40, 5)))
+    ref = _run(eng, 40, 17, x0, 12, 'solo')
+    monkeypatch.setenv('LCF_RUN_TEST_MISSING', '1')
+    monkeypatch.setenv('LCF_PEER_WAIT_S', '0.3')
+    got = _run(eng, 40, 17, x0, 12, 'auto')
+    assert got[0] == 'run' and got[4].last_run_kernel() == 'solo'
+    assert 'repeated with a launch per half-step' in capfd.readouterr().err
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    for a, b in zip(got[4].get_state(), ref[4].get_state()):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv('LCF_RUN_TEST_MISSING')
+    for s in (got[4], ref[4]):
+        s.run(12, 4, 'random', True)
+    assert got[4].last_run_kernel() == 'solo' and got[4].set_half_step_kernel('auto') == 'solo'
+    assert np.array_equal(got[4].get_chain()[0], ref[4].get_chain()[0]) and np.array_equal(got[4].naccepted(), ref[4].naccepted())
+
+
 @pytest.mark.parametrize('kernel', ['auto', 'solo', 'fused', 'phases'])
 @pytest.mark.parametrize('nwalkers,randomize', [(11, True), (13, False), (27, True)])
 def test_odd_ensembles_follow_emcee_split(nwalkers, randomize, kernel):
