@@ -3374,12 +3374,16 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 // proposal, where a proposal that the prior excludes costs nothing: measured per half-step, k_solo_run against k_solo,
 // configs[1]'s light curve with 512 / 1024 / 2048 / 4096 walkers 4.9 / 6.0 / 11.8 / 22.7 against 6.1 / 7.8 / 13.5 /
 // 23.6 us; configs[2] (four parts, 2048 proposals) 80.7 against 76.9 us -- the boundary it saves is 2 % of that launch.
+// Light curves of more than two parts gain little (3000 observations at times of their own, 8 parts, 1024 walkers: 21.8
+// against 23.0 us) and lose below a few hundred proposals (100 walkers: 15.2 against 13.0 us -- the rows' way through the
+// board costs more than the boundary of so small a launch): they take it from 256 to 512 proposals.
 constexpr int kRunSlots = 512;
 bool run_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
     static const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;   // (tests: several slots per workgroup)
     return !disabled && !s->run_off && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
-           (s->ds.n_half <= kRunSlots || (s->e->dp.n_parts <= 2 && s->ds.n_half <= 4 * kRunSlots) || any_size);
+           ((s->e->dp.n_parts <= 2 ? s->ds.n_half <= 4 * kRunSlots : s->ds.n_half >= kRunSlots / 2 && s->ds.n_half <= kRunSlots) ||
+            any_size);
 }
 
 struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; };

@@ -342,7 +342,7 @@ def test_long_light_curve_one_launch_and_phases():
     assert a.one_launch and NativeSampler(_setup(8)[3], 8, 1).one_launch
     a.set_state(x0)
     a.run(0, 3, 'random', True)
-    assert a.last_run_kernel() == 'run'
+    assert a.last_run_kernel() == 'solo'   # (more than two parts and 8 proposals: a launch per half-step)
     b = NativeSampler(eng, 16, 5)
     b.set_state(x0)
     b.begin(0, 3, 'random', True)

@@ -18,4 +18,4 @@ for nw in (100, 1024):
     s.set_state(bench.initial_walkers(nw))
     s.run(0, 20, 'random', False); s.run(20, 500, 'random', False)
     ms = s.last_run_ms() / 500
-    print(f'ragged 3000 points, {nw} walkers: {ms * 1e3:.1f} us per step, {nw / ms * 1e3 / 1e6:.2f}e6 walker-steps/s, one launch: {s.one_launch}')
+    print(f'ragged 3000 points, {nw} walkers: {ms * 1e3:.1f} us per step, {nw / ms * 1e3 / 1e6:.2f}e6 walker-steps/s, kernel {s.last_run_kernel()}')
