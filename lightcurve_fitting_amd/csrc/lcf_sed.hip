@@ -58,11 +58,14 @@ struct SedObs {
 };
 
 // ln S_f(T) from filter f's interpolant at the interval coordinate x (rows of 8 doubles; LDS or global memory)
-template <class RowPtr>
+// STRIDE: 16-byte words from row to row.  In LDS the rows are 80 bytes apart (kSedRowLds): the lanes of a wave are
+// candidates with temperatures of their own, so they read DIFFERENT rows, and rows 64 bytes apart put every lane's
+// first 16 bytes on the same 8 of the 32 banks (a 4-way conflict on each of the row's four reads).
+template <class RowPtr, int STRIDE = 4>
 __device__ __forceinline__ double sed_interp(RowPtr rows, int m, int f, double x) {
     const int j = (int)x;
     const double s = fma(__builtin_amdgcn_fract(x), 2., -1.);
-    const RowPtr q = rows + ((size_t)f * m + j) * 4;
+    const RowPtr q = rows + ((size_t)f * m + j) * STRIDE;
     const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     double g = fma(q0.x, s, q0.y);
     g = fma(g, s, q1.x);
@@ -89,6 +92,10 @@ __device__ __forceinline__ double sed_term(double y, double yfit, double dy, dou
 // (1536 workgroups of 256 staged 46 MB for 31 MB of candidates and results; 512 of 1024 stage 15 MB and fill the CU's
 // 32 wave slots with two workgroups)
 constexpr int kSedWide = 1024;
+#ifndef LCF_SED_ROW_LDS
+#define LCF_SED_ROW_LDS 5
+#endif
+constexpr int kSedRowLds = LCF_SED_ROW_LDS;   // 16-byte words per staged row of 8 coefficients (4 + padding)
 
 // precision 2, the fast part: every candidate whose temperature is inside the range of all its epoch's interpolants.
 // The unit of work is a WAVE: 64 candidates of one epoch (the epoch's observations are then wave-uniform: scalar loads);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(kSedWide) void k_sed_interp(const SedDev sd, const 
     double* exptab = reinterpret_cast<double*>(smem);
     double2* rows = reinterpret_cast<double2*>(smem + kExpTabSize * sizeof(double));
     for (int k = threadIdx.x; k < kExpTabSize; k += kSedWide) exptab[k] = sd.exp2tab[k];
-    for (int k = threadIdx.x; k < sd.n_filters * sd.itab_m * 4; k += kSedWide) rows[k] = sd.itab[k];
+    for (int k = threadIdx.x; k < sd.n_filters * sd.itab_m * 4; k += kSedWide) rows[(k >> 2) * kSedRowLds + (k & 3)] = sd.itab[k];
     __syncthreads();
     const ExpTab et{exptab};
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -153,8 +160,8 @@ __global__ __launch_bounds__(kSedWide) void k_sed_interp(const SedDev sd, const 
         for (int o = o0; o < o1; o += 2) {
             const int ob2 = min(o + 1, o1 - 1);
             const double4 ra = ob.rec[o], rb = ob.rec[ob2];
-            const double La = sed_interp(static_cast<const double2*>(rows), m, ob.filt[o], xs);
-            const double Lb = sed_interp(static_cast<const double2*>(rows), m, ob.filt[ob2], xs);
+            const double La = sed_interp<const double2*, kSedRowLds>(rows, m, ob.filt[o], xs);
+            const double Lb = sed_interp<const double2*, kSedRowLds>(rows, m, ob.filt[ob2], xs);
             const double ya = r2 * exp_scaled<false>(La * kInvLn2N, et), yb = r2 * exp_scaled<false>(Lb * kInvLn2N, et);
             const double ta = sed_term(ra.x, ya, ra.w, ra.y, ra.z, n_par > 2, sigma_abs ? su_abs : sig * ra.w);
             const double tb = sed_term(rb.x, yb, rb.w, rb.y, rb.z, n_par > 2, sigma_abs ? su_abs : sig * rb.w);
@@ -423,7 +430,7 @@ lcf_status lcf_sed_create(int32_t n_filters, const int32_t* tab_off, const doubl
     s->have_ctab = have_ctab;
     // the interpolants fit the fast kernel's LDS up to 19 filters (2 + 4 KiB each of 160); beyond that precision 2 is
     // not offered and the callers get the sample-table sums
-    s->have_itab = have_itab && (size_t)n_filters * itab_m * 64 + kExpTabSize * sizeof(double) <= 80 * 1024;
+    s->have_itab = have_itab && (size_t)n_filters * itab_m * 16 * kSedRowLds + kExpTabSize * sizeof(double) <= 80 * 1024;
     std::vector<double2> hitab;
     s->rmin.assign(n_filters, INFINITY);
     if (s->have_itab) {
@@ -552,7 +559,7 @@ lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int
         LCF_HIP(hipEventRecord(a, s->stream));
     }
     if (precision == 2) {
-        const size_t lds2 = kExpTabSize * sizeof(double) + (size_t)s->sd.n_filters * s->sd.itab_m * 64;
+        const size_t lds2 = kExpTabSize * sizeof(double) + (size_t)s->sd.n_filters * s->sd.itab_m * 16 * kSedRowLds;
         if (lds2 > 64 * 1024)
             LCF_HIP(hipFuncSetAttribute((const void*)k_sed_interp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // workgroups of 256 with a grid stride over the (epoch, tile) items: as many as keep every CU busy with the
