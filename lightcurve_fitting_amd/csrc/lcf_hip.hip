@@ -42,12 +42,6 @@
 #ifndef LCF_KPRE_SOLO
 #define LCF_KPRE_SOLO 2  // the same in the one-workgroup-per-proposal kernel (4: 3.73e7 walker-steps/s, 3: 3.74e7, 2: 3.78e7)
 #endif
-#ifndef LCF_RUN_AGENT
-#define LCF_RUN_AGENT 1       // (experiment) 0: the board of a one-launch run is polled and posted at system scope
-#endif
-#ifndef LCF_RUN_KEEP_COLS
-#define LCF_RUN_KEEP_COLS 1   // 1: k_solo_run keeps the lanes' first columns in registers across half-steps (spills)
-#endif
 #ifndef LCF_FIRST_BLOCK
 #define LCF_FIRST_BLOCK 32  // steps in the first block of draw records of a run (the later ones: up to 256)
 #endif
@@ -980,7 +974,7 @@ struct DevSampler {
     unsigned long long* board;
     unsigned long long* peer_board[kMaxPeers];
     int n_board_ranks, board_rank;
-    int ring, run_mode;   // versions a board keeps (a power of two); 1: the board of a one-launch run (k_solo_run), no peers
+    int ring, pad_ring;   // versions a board keeps (a power of two): kRing between ranks, kRunRing for one-launch runs
     // One-launch runs write the snapshot the host reads after a run -- [error word | X | LP | n_accepted] in pinned host
     // memory -- themselves, with the state, in their last step; a workgroup that meets a NaN or gives up a wait says so in
     // a word of its own behind it (snap_flags[blockIdx.x & (kSnapFlags - 1)] = 1 / snap_flags[kSnapFlags + ...] = 2;
@@ -1571,7 +1565,7 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
         const bool own = lane >= 16;
         const int col = own ? lane - 16 : lane;
         if (own ? col <= nd + 1 : col < nd)
-            h.got = board_take<BOARD == 2 && LCF_RUN_AGENT>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
+            h.got = board_take<BOARD == 2>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
     }
     h.lp_i = BOARD ? lane_value(h.got, 16 + nd) : sm.LP[dr.wid];
 #pragma unroll
@@ -1713,11 +1707,11 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
     if (tid < 64) {
         HeadRows<ND> rows;
         head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0);
-        if (kFetch && (first || !LCF_RUN_KEEP_COLS)) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
+        if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
     } else {
         if (LCF_HEAD_START > 0) __builtin_amdgcn_s_sleep(LCF_HEAD_START);
-        if (kFetch && (first || !LCF_RUN_KEEP_COLS)) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
+        if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
         // (a hint only: nothing depends on the value or on the placement).
@@ -1728,7 +1722,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         }
         if (!reddened && first) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
         LCF_STAMP(1, 11);
-        if (BOARD == 2 && tid == 64) sctl[0] = board_aborted<LCF_RUN_AGENT != 0>(sm) ? 1 : 0;   // (in the shadow of the head)
+        if (BOARD == 2 && tid == 64) sctl[0] = board_aborted<true>(sm) ? 1 : 0;   // (in the shadow of the head)
         if (BOARD == 1 && tid < 128) {
             // In the shadow of the head: has every rank finished half-step G - 2 (lane = rank)?  has this rank given up?
             const int lane = tid - 64;
@@ -1843,7 +1837,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         if (tid <= nd + 1) {
             const double v = tid < nd ? (ok ? sq[tid] : sx[tid]) : tid == nd ? (ok ? nlp : lp_i) : count;
             if (BOARD == 2) {
-                board_post<LCF_RUN_AGENT != 0>(sm.board, sm, (unsigned int)(G + 1), dr.wid, tid, v);
+                board_post<true>(sm.board, sm, (unsigned int)(G + 1), dr.wid, tid, v);
             } else {
 #pragma unroll
                 for (int r = 0; r < kMaxPeers; ++r)
@@ -1942,9 +1936,9 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
                 long long g_run0, int n_hs, long long state_from, int n_wg) {
     // (n_wg = gridDim.x, except in the test of a launch whose workgroups are not all there: LCF_RUN_TEST_MISSING)
     extern __shared__ __align__(16) unsigned char smem[];
-#if LCF_RUN_KEEP_COLS
+    // (a lane's first column: fetched by the launch's first half-step and kept -- 26 registers, a few of them spilled;
+    // fetching it again every half-step costs 0.5 us, in front of the head's own loads)
     ColumnOperands first_col;
-#endif
     typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
     const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     bool first = true;
@@ -1957,7 +1951,7 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
              w += n_wg * (int)(blockDim.x / 32))
             if (col <= nd + 1) {
                 const double v = col < nd ? sm.X[(size_t)w * nd + col] : col == nd ? sm.LP[w] : (double)sm.nacc[w];
-                board_post<LCF_RUN_AGENT != 0>(sm.board, sm, (unsigned int)g_run0, w, col, v);
+                board_post<true>(sm.board, sm, (unsigned int)g_run0, w, col, v);
             }
     }
 #pragma unroll 1
@@ -1966,9 +1960,6 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
 #pragma unroll 1
         for (int i = blockIdx.x; i < sm.n_half; i += n_wg) {
             if (draws[i].wid < 0) continue;   // (uniform) an odd ensemble's smaller colour leaves its last slot empty
-#if !LCF_RUN_KEEP_COLS
-            ColumnOperands first_col;         // (re-fetched per half-step, from L2: 26 registers that need not live on)
-#endif
             // the record this workgroup needs next: its next slot of this half-step, else its first of the next one
             const bool more = i + n_wg < sm.n_half;
             const DrawRec* hint = more ? draws + n_wg : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
@@ -3427,7 +3418,6 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
     rs.n_board_ranks = 1;
     rs.board_rank = 0;
     rs.ring = kRunRing;
-    rs.run_mode = 1;
     rs.snap_out = reinterpret_cast<unsigned long long*>(s->snap);
     rs.snap_flags = s->snap_flags();
     rs.X_out = s->alt_X;
@@ -3680,7 +3670,6 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     ds.a = a;
     ds.wait_ticks = peer_wait_ticks();
     ds.ring = kRing;
-    ds.run_mode = 0;
     const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
     lcf_status st;
 #define AL(p, n) if ((st = dalloc(&p, n, s->owned)) != LCF_OK) { delete s; return st; }
