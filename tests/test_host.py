@@ -309,6 +309,16 @@ def test_hot_kernels_neither_spill_nor_lose_occupancy():
         # -- every model's arithmetic and both column fast paths behind run-time switches -- under four
         assert int(f['SGPRs Spill']) <= (64 if k in special else 256), (k, f)
         assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
+    # k_solo_run (resident workgroups: the same half-step in a loop over up to 64 of them): what lives across the loop
+    # costs the benchmark kernels a few registers -- it must stay a few (spilled registers are scratch traffic in every
+    # half-step), and the occupancy that lets two workgroups share a CU must hold for every instantiation
+    runs = [k for k in blocks if re.search(r'k_solo_runILi[4-9]ELi1ELb1ELi[24]ELi[012]E', k)]
+    run_special = [k for k in runs if re.search(r'ELi[12]EEEv', k)]
+    assert len(runs) == 12 + 4 and len(run_special) == 4, sorted(blocks)[:5]
+    for k in runs:
+        f = blocks[k]
+        assert int(f['Occupancy']) >= 4 and int(f['VGPRs']) <= 128, (k, f)
+        assert int(f['VGPRs Spill']) <= 32 and int(f['ScratchSize']) <= 128, (k, f)
     # population mode's one launch per half-step, in the dimensions with their own instantiation
     pops = [k for k in blocks if re.search(r'k_popILi[4568]ELi1ELi4ELi[012]E', k)]
     assert len(pops) == 4 + 2, sorted(blocks)[:5]
