@@ -1705,10 +1705,16 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
     // (model-specialised kernels only: the generic ones need the registers for the point-by-point path)
     constexpr bool kFetch = MODEL != 0;
     if (tid < 64) {
+        // Resident workgroups drift apart, so this head shares its SIMD with column waves of the CU's other workgroup:
+        // the one wave that everybody behind it waits for goes first (5.75 against 6.03 us per half-step; with a launch
+        // per half-step both workgroups are in their heads at once and the priority only starves the staging waves:
+        // 8.06 against 7.71 us)
+        if (BOARD == 2) __builtin_amdgcn_s_setprio(3);
         HeadRows<ND> rows;
         head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0);
         if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
+        if (BOARD == 2) __builtin_amdgcn_s_setprio(0);
     } else {
         if (LCF_HEAD_START > 0) __builtin_amdgcn_s_sleep(LCF_HEAD_START);
         if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
@@ -1825,6 +1831,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         // rank's board; this rank's X / LP / counts follow for its own walkers (the others' come from the board when
         // the run ends, and the chain is written from the board)
         if (tid >= 64) return false;
+        if (BOARD == 2) __builtin_amdgcn_s_setprio(3);   // (the row's readers wait for this)
         double nlp = -INFINITY;
         if (!excluded) {
             double sum = pb.use_sigma ? 0. : pb.log_norm_const;
@@ -1871,6 +1878,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             atomicOr(sm.err, 1);
             if (BOARD == 2 && sm.snap_flags) sm.snap_flags[blockIdx.x & (kSnapFlags - 1)] = 1u;
         }
+        if (BOARD == 2) __builtin_amdgcn_s_setprio(0);
         LCF_STAMP(0, 10);
         return false;
     }
