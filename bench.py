@@ -548,6 +548,9 @@ def run_mcmc(args):
                               interp=(n_interp, N_EPOCHS) if n_interp else None)
         roof['half_steps_per_launch'] = hs_per_launch
         roof['kernel_ms_per_half_step'] = kern_ms / hs_per_launch
+        if world > 1:
+            roof['kernel'] += (" [one rank's share as a single-GPU run: the reference point of the multi-rank drivers, "
+                               'which launch k_solo<BOARD> / k_fused per half-step]')
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
