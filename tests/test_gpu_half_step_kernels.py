@@ -105,6 +105,30 @@ def test_resident_workgroups_with_several_slots_each(monkeypatch):
     assert np.array_equal(got[4].get_chain()[0], ref[4].get_chain()[0]) and np.array_equal(got[4].naccepted(), ref[4].naccepted())
 
 
+def test_two_runs_in_flight_keep_one_resident_launch_per_device():
+    """Two samplers on engines (streams) of their own, both runs enqueued before either is waited for: the resident
+    workgroups of two launches could keep each other off the device, so the second run -- enqueued while the first is in
+    flight -- takes a launch per half-step; both chains are the ones of runs that had the device to themselves."""
+    (pa, ea), (pb_, eb) = _multiband(seed=77), _multiband(seed=78)
+    assert ea is not eb
+    rng = np.random.default_rng(8)
+    xa = pa['truth'] * (1 + 0.05 * rng.standard_normal((64, 5)))
+    xb = pb_['truth'] * (1 + 0.05 * rng.standard_normal((64, 5)))
+    ref_a, ref_b = _run(ea, 64, 3, xa, 150, 'solo'), _run(eb, 64, 4, xb, 150, 'solo')
+    a, b = NativeSampler(ea, 64, 3), NativeSampler(eb, 64, 4)
+    a.set_state(xa)
+    b.set_state(xb)
+    a.run_async(0, 150, 'random', True)
+    b.run_async(0, 150, 'random', True)
+    a.wait()
+    b.wait()
+    assert a.last_run_kernel() == 'run' and b.last_run_kernel() == 'solo'
+    assert np.array_equal(a.get_chain()[0], ref_a[1]) and np.array_equal(b.get_chain()[0], ref_b[1])
+    assert np.array_equal(a.naccepted(), ref_a[3]) and np.array_equal(b.naccepted(), ref_b[3])
+    b.run(150, 10, 'random', True)       # (nothing in flight any more: resident workgroups again)
+    assert b.last_run_kernel() == 'run'
+
+
 def test_a_resident_launch_that_cannot_finish_is_repeated_launch_by_launch(monkeypatch, capfd):
     """k_solo_run's workgroups wait for each other, so all of them must be on the device at once.  When they are not
     (LCF_RUN_TEST_MISSING: the last workgroup is never launched -- as when another process's resident kernel holds the
