@@ -3375,13 +3375,15 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 // 23.6 us; configs[2] (four parts, 2048 proposals) 80.7 against 76.9 us -- the boundary it saves is 2 % of that launch.
 // Light curves of more than two parts gain little (3000 observations at times of their own, 8 parts, 1024 walkers: 21.8
 // against 23.0 us) and lose below a few hundred proposals (100 walkers: 15.2 against 13.0 us -- the rows' way through the
-// board costs more than the boundary of so small a launch): they take it from 256 to 512 proposals.
+// board costs more than the boundary of so small a launch; configs[2]'s light curve with 512 walkers: 14.1 against the 12.8 us
+// of the 1024-thread workgroups that k_solo uses for launches of at most one workgroup per CU): they take it above one
+// proposal per CU, up to 512.
 constexpr int kRunSlots = 512;
 bool run_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
     static const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;   // (tests: several slots per workgroup)
     return !disabled && !s->run_off && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
-           ((s->e->dp.n_parts <= 2 ? s->ds.n_half <= 4 * kRunSlots : s->ds.n_half >= kRunSlots / 2 && s->ds.n_half <= kRunSlots) ||
+           ((s->e->dp.n_parts <= 2 ? s->ds.n_half <= 4 * kRunSlots : s->ds.n_half > s->e->n_cus && s->ds.n_half <= kRunSlots) ||
             any_size);
 }
 

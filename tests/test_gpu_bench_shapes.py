@@ -90,7 +90,7 @@ def test_config2_chain_at_the_benchmark_shape():
     eng = model.engine_for(lc, priors=priors)
     x0 = bench.companion_walkers(512)
     s = EnsembleSampler(512, 8, eng, seed=bench.SEED)
-    assert s._native.set_half_step_kernel('auto') == 'run'
+    assert s._native.set_half_step_kernel('auto') == 'solo'   # (four parts, one proposal per CU: 1024-thread workgroups)
     s.run_mcmc(x0, 2)
     ref, ref_lp, ref_acc = O.stretch_move_run(log_posterior, x0, 2, bench.SEED)
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
