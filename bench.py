@@ -510,7 +510,10 @@ def run_mcmc(args):
     engine.set_variant(args.variant)
     engine._variant = args.variant
     scaling = args.scaling or 'weak'
-    n_walkers = WALKERS_PER_GPU * (world if scaling == 'weak' else 1)
+    # (a dry run with all ranks on ONE device: ensembles small enough that the ranks' launches fit the device side by
+    # side -- workgroups of one rank that wait for rows of another must not depend on the driver's time-slicing)
+    per_gpu = 256 if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1' else WALKERS_PER_GPU
+    n_walkers = per_gpu * (world if scaling == 'weak' else 1)
     x0 = initial_walkers(n_walkers)
     # The dominant kernel alone (HIP events over 2000 back-to-back launches), at this rank's share of a half-step when
     # the run is sharded.  Measured BEFORE the timed steps: a device that has just been handed over idles at low clocks,
@@ -632,7 +635,8 @@ def run_companion(args):
     from lightcurve_fitting_amd.sampler import EnsembleSampler
     model, lc, priors, lum0 = build_companion(local_rank)
     scaling = args.scaling or 'strong'
-    nw = COMPANION_WALKERS if scaling == 'strong' else 512 * world
+    one_device = os.environ.get('LCF_BENCH_ONE_DEVICE') == '1'   # (dry run: launches that fit the device side by side)
+    nw = (512 if one_device else COMPANION_WALKERS) if scaling == 'strong' else (128 if one_device else 512) * world
     engine = model.engine_for(lc, priors=priors)
     engine.set_variant(args.variant)
     engine._variant = args.variant
