@@ -10,6 +10,8 @@ from lightcurve_fitting_amd.engine import NativeSampler, LcfError
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 POOL = ['U', 'B', 'V', 'g', 'r', 'i', 'DLT40', 'z', 'UVW2', 'R', 'I']
 bad = []
+kernels = {}
+NS = int(os.environ.get('SOAK_STEPS', '3'))
 t0 = time.time()
 for seed in range(lo, hi):
     rng = np.random.default_rng(5000 + seed)
@@ -46,10 +48,11 @@ for seed in range(lo, hi):
     try:
         eng = m.engine_for(lc, use_sigma, 'relative', pri)
         x0 = truth * (1 + 0.03 * rng.standard_normal((nw, ndim)))
-        a = NativeSampler(eng, nw, seed); a.set_state(x0); a.run(0, 3, 'random', True)
-        b = NativeSampler(eng, nw, seed); b.set_state(x0); b.begin(0, 3, 'random', True)
-        c = NativeSampler(eng, nw, seed); c.set_state(x0); c.begin(0, 3, 'random', True)
-        for step in range(3):
+        a = NativeSampler(eng, nw, seed); a.set_state(x0); a.run(0, NS, 'random', True)
+        kernels[a.last_run_kernel()] = kernels.get(a.last_run_kernel(), 0) + 1
+        b = NativeSampler(eng, nw, seed); b.set_state(x0); b.begin(0, NS, 'random', True)
+        c = NativeSampler(eng, nw, seed); c.set_state(x0); c.begin(0, NS, 'random', True)
+        for step in range(NS):
             for half in (0, 1):
                 b.propose(step, half); b.evaluate(0, nw // 2); b.accept(step, half)
                 c.half_step_rows(step, half, 0, nw // 2); c.accept(step, half)
@@ -65,4 +68,4 @@ for seed in range(lo, hi):
         bad.append((seed, kind, len(t), nw, repr(exc)[:160]))
     if seed % 20 == 0:
         print('seed', seed, 'failures', len(bad), f'{time.time() - t0:.0f}s', flush=True)
-print('done', hi - lo, 'cases; failures:', bad)
+print('done', hi - lo, 'cases; kernels of the one-call run:', kernels, '; failures:', bad)
