@@ -1039,8 +1039,11 @@ __device__ inline double mbox_take(const DevSampler& sm, long long g, int slot, 
 // 50-bit Philox key (ties impossible: the walker id fills the low 14 bits) with a bitonic sort in LDS.
 // perm[step][0 .. n/2) is colour 0.  Deterministic in (seed, step): every rank of a multi-GPU run derives the same
 // split without communicating.
+// `slot_of` (or null): the slot table of k_slots, written here as well -- the step's two rows, and by the block's first
+// workgroup the row in front of the block (`front`, or all -1) -- so that the records need no launch in between.
 __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, uint32_t key0, uint32_t key1,
-                                                    long long first_step, int* __restrict__ perm) {
+                                                    long long first_step, int* __restrict__ perm, int n_half,
+                                                    int* __restrict__ slot_of, const int* __restrict__ front) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     const long long step = first_step + blockIdx.x;
@@ -1078,8 +1081,16 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
         }
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < n_walkers; w += blockDim.x)
-        perm[(size_t)blockIdx.x * n_walkers + w] = (int)(keys[w] & 0x3fffull);
+    for (int w = threadIdx.x; w < n_walkers; w += blockDim.x) {
+        const int wid = (int)(keys[w] & 0x3fffull);
+        perm[(size_t)blockIdx.x * n_walkers + w] = wid;
+        if (slot_of) {   // (position w of the permutation: colour 0 = the first n_half entries -- as k_slots)
+            const int half = w < n_half ? 0 : 1, slot = w < n_half ? w : w - n_half;
+            slot_of[((size_t)blockIdx.x * 2 + 1 + half) * n_walkers + wid] = slot;
+            slot_of[((size_t)blockIdx.x * 2 + 1 + (1 - half)) * n_walkers + wid] = -1;
+            if (blockIdx.x == 0) slot_of[w] = front ? front[w] : -1;
+        }
+    }
 }
 
 // Slot of every walker in each half-step of a block of steps (-1 where it is not active).  Rows of `slot_of`
@@ -3083,7 +3094,8 @@ lcf_status generate_steps(lcf_sampler* s, int buf, int64_t step0, int64_t len, i
         while (n_pad < ds.n_walkers) n_pad <<= 1;
         const int threads = std::min(1024, std::max(64, n_pad / 2));
         hipLaunchKernelGGL(k_make_perm, dim3((unsigned)len), dim3(threads), (size_t)n_pad * 8, gs, ds.n_walkers, n_pad,
-                           ds.key0, ds.key1, (long long)step0, s->d_perm[buf]);
+                           ds.key0, ds.key1, (long long)step0, s->d_perm[buf], ds.n_half,
+                           need_slots ? s->d_slot[buf] : nullptr, front);
         perm = s->d_perm[buf];
     } else if (split_mode == LCF_SPLIT_HOST) {
         perm = host_perm;
@@ -3092,8 +3104,9 @@ lcf_status generate_steps(lcf_sampler* s, int buf, int64_t step0, int64_t len, i
     int* slots = nullptr;
     if (need_slots) {
         slots = s->d_slot[buf];
-        hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gs, ds.n_walkers, ds.n_half, perm,
-                           (long long)len, slots, front);
+        if (split_mode != LCF_SPLIT_RANDOM)   // (a random split's table comes with its permutations, from k_make_perm)
+            hipLaunchKernelGGL(k_slots, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, gs, ds.n_walkers, ds.n_half, perm,
+                               (long long)len, slots, front);
     }
     const long long recs = (long long)len * 2 * ds.n_half;
     hipLaunchKernelGGL(k_draws, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, gs, ds, perm, slots,
