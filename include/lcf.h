@@ -218,7 +218,7 @@ int32_t lcf_sampler_one_launch(const lcf_sampler* s);
 /* Which kernels a single-GPU run (lcf_sampler_run / _run_async) may use for a half-step.  All of them produce the
  * same chain bit for bit; the choice exists for tests and measurements.
  *   AUTO:   one workgroup per proposal that also accepts / rejects, resident for a whole block of half-steps
- *           (k_solo_run: ONE launch per up to 60 steps, rows handed from workgroup to workgroup through a board of
+ *           (k_solo_run: ONE launch per up to 32 steps (64 half-steps), rows handed from workgroup to workgroup through a board of
  *           tagged rows in device memory) where a proposal's parts fit one workgroup; else one workgroup per
  *           (proposal, part) and launch (k_fused); else proposal + likelihood launches
  *   SOLO:   as AUTO, but one launch per half-step (k_solo)

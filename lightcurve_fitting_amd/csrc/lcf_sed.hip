@@ -180,16 +180,16 @@ __device__ inline void sed_rest_one(const SedDev& sd, const SedObs& ob, long lon
 // that filter's holds and through the (Gauss-compressed or full) sample table where it does not.  Tables from memory.
 __global__ __launch_bounds__(kSedBlock) void k_sed_rest(const SedDev sd, const SedObs ob, long long n_cand, int n_par,
                                                         int sigma_abs, int use_ctab, const double* __restrict__ cand,
-                                                        double* __restrict__ out, const unsigned int* __restrict__ n_rest,
+                                                        double* __restrict__ out, unsigned int* n_rest,
                                                         const long long* __restrict__ rest) {
     __shared__ double exptab[kExpTabSize];
     const unsigned int n_list = *n_rest;
     // (n_rest[1] counts the workgroups that have read the list's length: the last one clears both words for the next
     // call -- a fill launch of 4 us in front of a 30 us kernel otherwise)
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(const_cast<unsigned int*>(n_rest) + 1, 1u) == gridDim.x - 1) {
-        const_cast<unsigned int*>(n_rest)[0] = 0u;
-        const_cast<unsigned int*>(n_rest)[1] = 0u;
+    if (threadIdx.x == 0 && atomicAdd(n_rest + 1, 1u) == gridDim.x - 1) {
+        n_rest[0] = 0u;
+        n_rest[1] = 0u;
     }
     if ((unsigned int)(blockIdx.x * kSedBlock) >= n_list) return;
     for (int k = threadIdx.x; k < kExpTabSize; k += kSedBlock) exptab[k] = sd.exp2tab[k];
@@ -342,6 +342,7 @@ struct lcf_sed {
     long long n_obs = 0;
     bool have_itab = false;
     std::vector<float> rmin;            // per filter, host copy (the epochs' thresholds are made from it)
+    bool nrest_dirty = false;           // a call ended between k_sed_interp and the completion of k_sed_rest: the words are stale
     unsigned int* d_nrest = nullptr;    // precision 2: how many candidates the fast kernel left to k_sed_rest ...
     long long* d_rest = nullptr;        // ... and which (capacity: out_cap)
 
@@ -568,6 +569,10 @@ lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int
         const long long per_cu = std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024 / std::max<size_t>(lds2, 1))));
         const long long wpg = kSedWide / 64;
         const unsigned groups = (unsigned)std::max<long long>(1, std::min<long long>((items + wpg - 1) / wpg, 256 * per_cu));
+        // (the list's words are cleared by k_sed_rest's last workgroup; a call that failed before that left them stale --
+        // the next append would start behind the stale length, past the list's capacity)
+        if (s->nrest_dirty) LCF_HIP(hipMemsetAsync(s->d_nrest, 0, 2 * sizeof(unsigned int), s->stream));
+        s->nrest_dirty = true;
         hipLaunchKernelGGL(k_sed_interp, dim3(groups), dim3(kSedWide), lds2, s->stream, s->sd, s->ob, (long long)n_cand,
                            n_par, sigma_type == LCF_SIGMA_ABSOLUTE, s->dcand, s->dout, s->d_nrest, s->d_rest);
         // (a fixed, small grid with a stride over the list: its length stays on the device, and usually it is short)
@@ -584,6 +589,7 @@ lcf_status lcf_sed_log_likelihood(lcf_sed* s, int64_t n_cand, int32_t n_par, int
     if (kernel_ms) LCF_HIP(hipEventRecord(b, s->stream));
     LCF_HIP(hipMemcpyAsync(out, s->dout, no * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     LCF_HIP(hipStreamSynchronize(s->stream));
+    s->nrest_dirty = false;   // (both kernels of a precision-2 call have completed)
     if (kernel_ms) {
         float ms = 0.f;
         LCF_HIP(hipEventElapsedTime(&ms, a, b));

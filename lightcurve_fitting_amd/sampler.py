@@ -246,7 +246,7 @@ COLLECTIVES = ('rows', 'peers', 'allgather')
 _probe_cache = {}   # (process group, world size) -> the driver the first probe in that group selected
 
 
-def probe_collectives(make_sampler, dist, x0, probe_steps=20, group=None, modes=COLLECTIVES):
+def probe_collectives(make_sampler, dist, x0, probe_steps=20, group=None, modes=COLLECTIVES, device=None):
     """Which multi-rank driver runs an ensemble fastest on THIS node: every driver in ``modes`` gets a few untimed steps
     from ``x0`` on a sampler of its own (``make_sampler(mode)``); one that raises on any rank (its waits are bounded),
     that could not connect its peer memory, or that leaves the ranks with different replicas of the ensemble is out; of
@@ -254,10 +254,13 @@ def probe_collectives(make_sampler, dist, x0, probe_steps=20, group=None, modes=
 
     Every rank takes the same path: success is AGREED (all-reduce of a flag) after the sampler is made, after its first
     short run and after the probe run, and a stage is skipped on every rank as soon as one rank failed the one before
-    -- a rank that raised never sits in a different collective than the ranks that did not."""
+    -- a rank that raised never sits in a different collective than the ranks that did not.
+
+    ``device``: where the flags of those agreements live (``'cuda:<n>'`` of this rank's engine under RCCL; default: the
+    current CUDA device under RCCL, the CPU otherwise)."""
     import time
     import torch
-    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    dev = device if device is not None else ('cuda' if dist.get_backend(group) == 'nccl' else 'cpu')
 
     def agreed(ok):   # logical AND over the ranks
         flag = torch.tensor([1. if ok else 0.], dtype=torch.float64, device=dev)
@@ -340,10 +343,12 @@ class EnsembleSampler:
         #: how the ranks of a multi-GPU run work together: 'rows' (every rank moves its share of the walkers with k_solo
         #: and stores their new rows into every rank's board over IPC-mapped memory), 'peers' (every rank evaluates its
         #: share, stores partial sums into every mailbox, replicates the bookkeeping), 'allgather' (the same with one RCCL
-        #: all-gather per half-step), or 'auto' (default; LCF_COLLECTIVE overrides): the first run of the first sampler
-        #: of a process group probes all three for a few steps (probe_collectives) and the group keeps the fastest
+        #: all-gather per half-step; the default -- the only driver whose wire protocol is RCCL's own), or 'auto'
+        #: (``collective='auto'`` / LCF_COLLECTIVE=auto): the first run of the first sampler of a process group probes
+        #: all of them for a few steps (probe_collectives) and the group keeps the fastest that works.  The peer-memory
+        #: drivers stay opt-in until an 8-GPU run has timed them (bench.py --gpus N probes by default and says what it saw).
         import os
-        self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'auto')
+        self.collective = collective or os.environ.get('LCF_COLLECTIVE', 'allgather')
         if self.collective not in COLLECTIVES + ('auto',):
             raise ValueError("collective must be 'auto', 'allgather', 'peers' or 'rows'")
         self.collective_probe = None   # the report of the probe this sampler ran (None: named, cached or single rank)
@@ -461,7 +466,9 @@ class EnsembleSampler:
         """'auto' -> the driver this process group runs fastest: probed once per group (on samplers of their own, a few
         steps from this sampler's present state), then remembered.  Every rank gets here at the same run."""
         import torch.distributed as dist
-        key = (id(self._group), dist.get_world_size(self._group))
+        # (the fastest driver depends on the shape of a half-step -- walkers, parameters, parts of the light curve --, not
+        # only on the node: one probe per group AND shape)
+        key = (id(self._group), dist.get_world_size(self._group), self.nwalkers, self.ndim, self._native.rows_ptr()[1])
         if key not in _probe_cache:
             x0 = self._native.get_state()[0]
             made = []
@@ -471,10 +478,25 @@ class EnsembleSampler:
                                             randomize_split=self.randomize_split, group=self._group, collective=mode,
                                             native_collectives=self.native_collectives))
                 return made[-1]
-            _, self.collective_probe = probe_collectives(make, dist, x0, group=self._group)
+            dev = f'cuda:{self.engine.device}' if dist.get_backend(self._group) == 'nccl' else 'cpu'
+            _, self.collective_probe = probe_collectives(make, dist, x0, group=self._group, device=dev)
             _probe_cache[key] = self.collective_probe['selected']
+            # The probe samplers own peer-mapped memory (boards, mailboxes) that other ranks may still be writing into:
+            # every rank has finished its probe runs before any rank unmaps anything, and the unmapping is explicit
+            # (not left to the garbage collector's order).
+            dist.barrier(group=self._group)
+            for s in made:
+                s.close()
             made.clear()
+            dist.barrier(group=self._group)
         self.collective = _probe_cache[key]
+
+    def close(self):
+        """Release the native sampler (device buffers, peer mappings) now instead of at garbage collection."""
+        if self._comm:
+            self._comm.close()
+        self._comm = False
+        self._native.close()
 
     def _distributed(self):
         try:
@@ -570,6 +592,7 @@ class EnsembleSampler:
             else:
                 self._native.run(self._steps_done, nsteps, split, store)
         except Exception as exc:
+            self._acc_seen = None   # (see _finish)
             if getattr(exc, 'status', None) == 6:
                 raise ValueError('Probability function returned NaN') from None
             raise
@@ -579,6 +602,7 @@ class EnsembleSampler:
             if self._in_flight:
                 self._native.wait()
         except Exception as exc:
+            self._acc_seen = None   # (a run that ended midway: the counts on the device are not what the last run left)
             if getattr(exc, 'status', None) == 6:
                 raise ValueError('Probability function returned NaN') from None
             raise
