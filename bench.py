@@ -255,7 +255,7 @@ def quiet_interpreter():
 
 def pick_collective(make_sampler, dist, x0, args):
     """N > 1: the sampler that runs the timed steps.  `--collective auto` = the library's own probe
-    (lightcurve_fitting_amd.sampler.probe_collectives: what EnsembleSampler(collective=None) runs on its first multi-rank
+    (lightcurve_fitting_amd.sampler.probe_collectives: what EnsembleSampler(collective='auto') runs on its first multi-rank
     run), here with the bench's sampler factory so that the selected sampler itself runs the timed steps and the report
     goes into the line."""
     if dist is None or args.collective != 'auto':

@@ -274,6 +274,14 @@ __device__ unsigned long long g_stamps[64 * 16];
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
         if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) g_stamps[blockIdx.x * 16 + (k)] = t_;                  \
     } while (0)
+#elif defined(LCF_PROGRESS)
+// Diagnostic build (-DLCF_PROGRESS; never shipped): how often each workgroup has passed each stamp -- where the
+// workgroups of a launch that cannot finish are.
+__device__ unsigned int g_progress[64 * 16];
+#define LCF_STAMP(W, k)                                                                                        \
+    do {                                                                                                       \
+        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) atomicAdd(&g_progress[blockIdx.x * 16 + (k)], 1u);    \
+    } while (0)
 #else
 #define LCF_STAMP(W, k) do {} while (0)
 #endif
@@ -990,7 +998,18 @@ struct DevSampler {
     // clock: peer_wait_ticks().  A rank's stream holds only a few ms of launches, so a host that stalls longer than
     // this on ONE rank ends the run on ALL of them -- the default is therefore seconds, not the 0.5 s of round 2.
     unsigned long long wait_ticks;
+    // ... and of the wait of a resident launch (k_solo_run) for the REST OF ITSELF: LCF_RESIDENT_WAIT_S, default 0.05 s.
+    unsigned long long resident_ticks;
 };
+
+// LCF_RESIDENT_WAIT_S (seconds, default 0.05): how long a workgroup of a resident launch waits for a row before it asks
+// whether the launch's other workgroups have started at all (board_take)
+unsigned long long resident_wait_ticks() {
+    double sec = 0.05;
+    if (const char* env = std::getenv("LCF_RESIDENT_WAIT_S")) sec = std::atof(env);
+    if (!(sec > 0.)) sec = 0.05;
+    return (unsigned long long)(std::min(sec, 600.) * 1e8);
+}
 
 // LCF_PEER_WAIT_S (seconds, default 5; the tests of the bounded waits set 0.5)
 unsigned long long peer_wait_ticks() {
@@ -1424,44 +1443,71 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
     if (sm.n_peers > 0 && tid == 0) mbox_post(sm, g, i, part, part_stride(pb), psum);  // straight into every rank's mailbox
 }
 
-// ---- row boards: tagged words in uncached memory ------------------------------------------------------------------
-// One float64 = two 8-byte granules {32 data bits, 32-bit tag}, tag = half-step after which the row holds + 1 (the LL
-// protocol of the mailboxes above); version ring of kRing half-steps.  Safe because (a) a reader asks for exactly the
-// version the draw record names (DrawRec::wage / page) and waits, bounded, until both granules carry its tag; (b) no rank
-// starts half-step G before every rank has finished G - 2 (progress words, posted by the first workgroup of a rank's
-// NEXT launch: stream order proves that the launch before it is complete): half-steps G - 1 and G are the only ones in
-// flight anywhere, they read versions >= G - 3 and write G and G + 1, so eight versions are never overrun.
-constexpr int kRing = 8;
+// ---- row boards: tagged words in device memory ---------------------------------------------------------------------
+// One float64 = ONE 16-byte entry of two 8-byte granules {32 data bits, 32-bit tag}, tag = half-step after which the row
+// holds + 1 (the LL protocol of the mailboxes above, the entry posted with one 16-byte store and polled with one 16-byte
+// load: each granule carries its own tag, so an entry that arrives in two halves is still never mistaken for complete).
+// A row = the walker's n_dim + 2 numbers in consecutive entries, padded to whole 128-byte lines (board_row_entries):
+// the lanes of ONE store instruction post a row, into one line (n_dim <= 6) of each board it goes to.
+// Between ranks (k_solo<BOARD> per half-step, k_solo_run<..., RANKS> per block of half-steps): a ring of kRing versions.
+// Safe because (a) a reader asks for exactly the version the draw record names (DrawRec::wage / page) and waits,
+// bounded, until both granules carry its tag; (b) progress words bound how far ranks drift apart: with a launch per
+// half-step no rank starts half-step G before every rank has finished G - 2; with a launch per block of up to kRunSpan
+// half-steps no rank starts a launch before every rank has STARTED the launch before the previous one (a rank's
+// progress word = the first half-step of the launch it has reached, posted by that launch itself: stream order proves
+// that everything in front of it, its row collection included, is complete).  Everything a rank still reads is then at
+// most 3 kRunSpan + 2 versions behind anything another rank writes: kRing = 256 versions are never overrun.
+constexpr int kRing = 256;
 constexpr int kSnapFlags = 1024;
-// One-launch runs (k_solo_run): a launch covers at most kRunSpan half-steps, reads versions >= G - 3 and writes G + 1:
-// kRunRing versions are never overrun however far the workgroups of a launch drift apart.
+// One-launch runs of ONE GPU (k_solo_run): a launch covers at most kRunSpan half-steps, reads versions >= G - 3 and
+// writes G + 1: kRunRing versions are never overrun however far the workgroups of a launch drift apart.
 constexpr int kRunRing = 128;
 constexpr int kRunSpan = 64;
-constexpr int kBoardTail = kMaxPeers + 1 + 4;   // 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis
+constexpr int kRunStoreChain = 1, kRunFlip = 2;   // k_solo_run's run_flags: the run stores its chain; its start state is in X_out / LP_out / nacc_out
+// 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis, arrivals (workgroups of resident launches that
+// have started, counted up from launch to launch: a launch knows the count that says "all of mine are there")
+constexpr int kBoardTail = kMaxPeers + 1 + 4 + 1 + 4;
+constexpr int kBoardClear = 10;                 // the last words of the tail that set_state clears: abort ... arrivals, and
+                                                // the four words of the entry a given-up wait last saw (diagnosis)
+static_assert(kRing >= 3 * kRunSpan + 8, "the ring of the inter-rank boards must cover three launches");
 
-__device__ inline size_t board_rows_words(const DevSampler& sm) {
-    return (size_t)sm.ring * sm.n_walkers * (sm.n_dim + 2) * 2;   // 8-byte words
+__host__ __device__ inline int board_row_entries(int n_dim) { return (n_dim + 2 + 7) & ~7; }   // 16-byte entries per row
+__host__ __device__ inline size_t board_rows_bytes(int ring, int n_walkers, int n_dim) {
+    return (size_t)ring * n_walkers * board_row_entries(n_dim) * 16;
 }
 __device__ inline unsigned long long* board_entry(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid,
                                                   int col) {
-    return board + 2 * ((((size_t)(tag & (unsigned int)(sm.ring - 1)) * sm.n_walkers) + wid) * (sm.n_dim + 2) + col);
+    return board + 2 * ((((size_t)(tag & (unsigned int)(sm.ring - 1)) * sm.n_walkers) + wid) * board_row_entries(sm.n_dim) + col);
 }
 __device__ inline unsigned int* board_progress(unsigned long long* board, const DevSampler& sm) {
-    return reinterpret_cast<unsigned int*>(board + board_rows_words(sm));
+    return reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(board) +
+                                           board_rows_bytes(sm.ring, sm.n_walkers, sm.n_dim));
 }
-// AGENT: the board of a one-launch run lives in this GPU's ordinary memory and is shared by its own workgroups only:
-// device scope (the loads and stores meet behind the XCDs' L2s) instead of system scope.
+// 16-byte accesses past every cache (sc0 sc1 = system scope: they meet in memory, whichever XCD or GPU the other side
+// is on).  The store is not waited for; the load is (a poll has nothing else to do).  Written as instructions because
+// the language has no 16-byte atomic: the hardware moves an aligned 16-byte lane access as one piece, and the tags make
+// even 8-byte pieces safe.
+typedef unsigned int lcf_u32x4 __attribute__((ext_vector_type(4)));
+// AGENT: the board of a one-launch run lives in this GPU's ordinary memory and is shared by its own workgroups only.
+// Its 16-byte accesses are nevertheless issued at system scope (sc0 sc1), like those of the inter-rank boards: with sc1
+// alone (device scope) the same run takes TWICE as long (0.70 against 0.37 ms per launch of 64 half-steps at configs[1]
+// -- polls served from a cache for a while before they see memory); only the 4-byte words of the tail keep the scope.
+template <bool AGENT>
+__device__ __forceinline__ void store16_past_caches(unsigned long long* p, unsigned long long lo, unsigned long long hi) {
+    const lcf_u32x4 v = {(unsigned int)lo, (unsigned int)(lo >> 32), (unsigned int)hi, (unsigned int)(hi >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <bool AGENT>
+__device__ __forceinline__ void load16_past_caches(const unsigned long long* p, unsigned long long& lo, unsigned long long& hi) {
+    lcf_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+}
 template <bool AGENT = false>
 __device__ inline void board_post(unsigned long long* board, const DevSampler& sm, unsigned int tag, int wid, int col, double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
-    unsigned long long* p = board_entry(board, sm, tag, wid, col);
-    if (AGENT) {
-        __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    store16_past_caches<AGENT>(board_entry(board, sm, tag, wid, col), (b & 0xffffffffull) | t, (b >> 32) | t);
 }
 template <bool AGENT = false>
 __device__ inline bool board_aborted(const DevSampler& sm) {
@@ -1469,7 +1515,9 @@ __device__ inline bool board_aborted(const DevSampler& sm) {
     return (AGENT ? __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                   : __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
 }
-// (what: 1 = a row, a = tag, b = walker, c = column; 2 = the progress words, a = half-step, b = rank that is behind)
+__device__ inline unsigned int* board_arrivals(const DevSampler& sm) { return board_progress(sm.board, sm) + kMaxPeers + 5; }
+// (what: 1 = a row, a = tag, b = walker, c = column; 2 = the progress words, a = half-step, b = rank that is behind;
+// 3 = a row again, but the launch's workgroups were not all resident after DevSampler::resident_ticks: c = how many were)
 __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsigned int a, unsigned int b, unsigned int c) {
     unsigned int* flag = board_progress(sm.board, sm) + kMaxPeers;
     if (atomicCAS_system(flag, 0u, 1u) == 0u) {   // the first one to give up says what it was waiting for
@@ -1483,21 +1531,40 @@ __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsi
 }
 // The number with tag `tag` from this rank's board, once it is there (bounded wait: DevSampler::wait_ticks, then the launch is aborted
 // and the run ends with an error; NaN after an abort).
+// `arrive_goal` != 0 (resident launches): the value of the arrivals word from which all workgroups of this launch have
+// started.  Rows of a launch whose workgroups are all resident arrive within microseconds; a wait that has lasted
+// DevSampler::resident_ticks (50 ms) looks at the word ONCE: all there -> keep waiting (a stalled peer rank, a busy
+// device); not all there -> the launch cannot make progress (another resident kernel holds the CUs): give up now.
 template <bool AGENT = false>
-__device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col) {
+__device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col, unsigned int arrive_goal = 0u) {
     const unsigned long long* p = board_entry(sm.board, sm, tag, wid, col);
     const unsigned long long t0 = wall_clock64();
+    bool resident = arrive_goal == 0u;
     for (int spin = 0;; ++spin) {
-        const unsigned long long a = AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long b = AGENT ? __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long a, b;
+        load16_past_caches<AGENT>(p, a, b);
         if ((unsigned int)(a >> 32) == tag && (unsigned int)(b >> 32) == tag)
             return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
         if ((spin & 15) == 15) {
             if (board_aborted<AGENT>(sm)) return qnan();
+            if (!resident && wall_clock64() - t0 > sm.resident_ticks) {
+                const unsigned int there = __hip_atomic_load(board_arrivals(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(there - arrive_goal) < 0) {
+                    board_abort(sm, 3u, tag, (unsigned int)wid, there);
+                    return qnan();
+                }
+                resident = true;
+            }
             if (wall_clock64() - t0 > sm.wait_ticks) {
+                const bool was_first = !board_aborted<AGENT>(sm);
                 board_abort(sm, 1u, tag, (unsigned int)wid, (unsigned int)col);
+                if (was_first) {   // (what the entry holds instead: an older tag = never posted)
+                    unsigned int* seen = board_arrivals(sm) + 1;
+                    seen[0] = (unsigned int)a;
+                    seen[1] = (unsigned int)(a >> 32);
+                    seen[2] = (unsigned int)b;
+                    seen[3] = (unsigned int)(b >> 32);
+                }
                 return qnan();
             }
         }
@@ -1566,7 +1633,7 @@ struct HeadRows {
 
 template <int ND, int BOARD = 0>
 __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSampler& sm, const DrawRec& dr, int lane,
-                                           HeadRows<ND>& h, long long G = 0, long long g_run0 = 0) {
+                                           HeadRows<ND>& h, long long G = 0, long long g_run0 = 0, unsigned int arrive_goal = 0u) {
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const double* xs = sm.X + (size_t)dr.wid * nd;
@@ -1576,7 +1643,7 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
         const bool own = lane >= 16;
         const int col = own ? lane - 16 : lane;
         if (own ? col <= nd + 1 : col < nd)
-            h.got = board_take<BOARD == 2>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col);
+            h.got = board_take<BOARD == 2>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col, arrive_goal);
     }
     h.lp_i = BOARD ? lane_value(h.got, 16 + nd) : sm.LP[dr.wid];
 #pragma unroll
@@ -1681,7 +1748,8 @@ template <int ND, int VARIANT, bool THERM, int NPARTS, int BOARD, int MODEL>
 __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevProblem* __restrict__ pbp, const DevSampler& sm, long long row,
                                                const DrawRec* __restrict__ draws, const DrawRec* draws_next, long long G,
                                                long long g_run0, int i, unsigned char* smem, ColumnOperands& first_col,
-                                               bool first, bool write_state, const int tid) {
+                                               bool first, bool write_state, const int tid, const int run_flags = 0,
+                                               const unsigned int arrive_goal = 0u) {
     double* exptab = reinterpret_cast<double*>(smem);
     double* red = exptab + kExpTabSize;                                     // 4 wave sums per part (32 reserved)
     double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
@@ -1722,7 +1790,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         // 8.06 against 7.71 us)
         if (BOARD == 2) __builtin_amdgcn_s_setprio(3);
         HeadRows<ND> rows;
-        head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0);
+        head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0, arrive_goal);
         if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
         if (BOARD == 2) __builtin_amdgcn_s_setprio(0);
@@ -1864,9 +1932,11 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             // (a one-launch run writes the state in its last step only: every walker moves exactly once there, while two
             // moves of a walker in one launch come from different workgroups, and whose store reaches memory last is open)
             if (BOARD != 2 || write_state) {
-                double* X = BOARD == 2 ? sm.X_out : sm.X;
-                double* LP = BOARD == 2 ? sm.LP_out : sm.LP;
-                long long* nacc = BOARD == 2 ? sm.nacc_out : sm.nacc;
+                // (one-launch runs: into the set of state buffers the run did NOT start from -- kRunFlip says which)
+                const bool to_out = BOARD == 2 && !(run_flags & kRunFlip);
+                double* X = to_out ? sm.X_out : sm.X;
+                double* LP = to_out ? sm.LP_out : sm.LP;
+                long long* nacc = to_out ? sm.nacc_out : sm.nacc;
                 if (tid < nd)
                     X[(size_t)dr.wid * nd + tid] = v;
                 else if (tid == nd)
@@ -1880,7 +1950,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
                     else sm.snap_out[1 + nw * nd + nw + dr.wid] = (unsigned long long)(long long)v;
                 }
             }
-            if (BOARD == 2 && sm.store_chain) {   // (one GPU: every walker's row is decided here)
+            if (BOARD == 2 && (run_flags & kRunStoreChain)) {   // (one GPU: every walker's row is decided here)
                 if (tid < nd) sm.chain[((size_t)row * sm.n_walkers + dr.wid) * nd + tid] = v;
                 else if (tid == nd) sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = v;
             }
@@ -1951,25 +2021,38 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
 // half-steps (DevSampler::ring), so no workgroup can overrun a version another one still waits for.
 template <int ND, int VARIANT, bool THERM, int NPARTS, int MODEL>
 __global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
-void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long long rel0, const DrawRec* __restrict__ draws0,
-                long long g_run0, int n_hs, long long state_from, int n_wg) {
+void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler* __restrict__ smp, long long rel0,
+                const DrawRec* __restrict__ draws0, long long g_run0, int n_hs, long long state_from, int n_wg, int run_flags,
+                unsigned int arrive_goal) {
     // (n_wg = gridDim.x, except in the test of a launch whose workgroups are not all there: LCF_RUN_TEST_MISSING)
     extern __shared__ __align__(16) unsigned char smem[];
     // (a lane's first column: fetched by the launch's first half-step and kept -- 26 registers, a few of them spilled;
     // fetching it again every half-step costs 0.5 us, in front of the head's own loads)
     ColumnOperands first_col;
+    // Problem AND sampler are read through constant-address-space pointers: scalar loads where a field is used.  As
+    // kernel arguments the sampler's 60 words stayed in scalar registers across the loop over the half-steps -- and
+    // most of them in spill lanes.  What varies from run to run travels in `run_flags`, so that the copy in device
+    // memory is written once per sampler (lcf_sampler::run_image).
     typedef const DevProblem __attribute__((address_space(4)))* ProblemPtr;
+    typedef const DevSampler __attribute__((address_space(4)))* SamplerPtr;
     const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
+    const DevSampler& sm = *(const DevSampler*)(SamplerPtr)smp;
     bool first = true;
+    // "this workgroup has started": what a workgroup that waits unusually long for a row looks at (board_take)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(board_arrivals(sm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rel0 == 0) {
         // The run's first launch: the state in front of it is version g_run0 of every row (what a draw record's age
         // points at until the walker has moved in this run).  Whoever needs a row polls for it: no barrier behind this.
         const int nd = ND > 0 ? ND : sm.n_dim;
         const int col = threadIdx.x & 31;   // (n_dim + 2 <= kMaxDim + 2 columns)
+        const bool flip = (run_flags & kRunFlip) != 0;
+        const double* X = flip ? sm.X_out : sm.X;
+        const double* LP = flip ? sm.LP_out : sm.LP;
+        const long long* nacc = flip ? sm.nacc_out : sm.nacc;
         for (int w = blockIdx.x * (int)(blockDim.x / 32) + (int)(threadIdx.x / 32); w < sm.n_walkers;
              w += n_wg * (int)(blockDim.x / 32))
             if (col <= nd + 1) {
-                const double v = col < nd ? sm.X[(size_t)w * nd + col] : col == nd ? sm.LP[w] : (double)sm.nacc[w];
+                const double v = col < nd ? X[(size_t)w * nd + col] : col == nd ? LP[w] : (double)nacc[w];
                 board_post<true>(sm.board, sm, (unsigned int)g_run0, w, col, v);
             }
     }
@@ -1985,11 +2068,22 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler sm, long lo
             const int tid = threadIdx.x;
             if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pb, pbp, sm, (rel0 + h) >> 1, draws, hint,
                                                                      g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
-                                                                     rel0 + h >= state_from, tid))
+                                                                     rel0 + h >= state_from, tid, run_flags, arrive_goal))
                 return;
             first = false;
         }
     }
+}
+
+// The images of DevProblem / DevSampler that kernels read through constant-address-space pointers are WRITTEN BY A
+// KERNEL on the stream of the launches that read them: ordinary producer -> consumer order between two kernels of one
+// queue.  (A host copy into an image whose address an earlier one had -- a sampler destroyed, the next created -- left
+// some workgroups of the next launch with the old struct out of an XCD's L2: rows posted for another board layout, a
+// launch that waited for them for ever.  Seen once the inter-rank boards grew and allocations started to recycle
+// addresses; tools/debug/rows_mismatch.py.)
+template <class T>
+__global__ void k_put_image(T* __restrict__ dst, const T src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src;
 }
 
 // State of the sampler as 8-byte words into (mapped, pinned) host memory: [error flag | X | LP | n_accepted].
@@ -2191,14 +2285,7 @@ struct lcf_engine {
     bool have_ctab = false, have_itab = false;
     int n_cus = 256;             // compute units of the device (launch shapes depend on it)
     DevProblem* d_dp = nullptr;  // `dp` in device memory, for the kernels that read it through a pointer
-    lcf_status sync_dp() {       // after every change of `dp`
-        if (!d_dp) {
-            LCF_HIP(hipMalloc((void**)&d_dp, sizeof(DevProblem)));
-            owned.push_back(d_dp);
-        }
-        LCF_HIP(hipMemcpy(d_dp, &dp, sizeof(DevProblem), hipMemcpyHostToDevice));
-        return LCF_OK;
-    }
+    lcf_status sync_dp();        // after every change of `dp`
     // workspace for n walkers
     int64_t cap = 0;
     double *wP = nullptr, *wcoef = nullptr, *wlprior = nullptr, *wpart = nullptr, *wout = nullptr;
@@ -2248,6 +2335,19 @@ struct lcf_engine {
         return LCF_OK;
     }
 };
+
+// `dp` into its image in device memory: by a kernel on the engine's stream (see k_put_image), complete on return.
+lcf_status lcf_engine::sync_dp() {
+    if (!d_dp) {
+        LCF_HIP(hipMalloc((void**)&d_dp, sizeof(DevProblem)));
+        owned.push_back(d_dp);
+    }
+    LCF_HIP(hipDeviceSynchronize());   // (nothing in flight reads the old image)
+    hipLaunchKernelGGL(k_put_image<DevProblem>, dim3(1), dim3(64), 0, stream, d_dp, dp);
+    LCF_HIP(hipGetLastError());
+    LCF_HIP(hipStreamSynchronize(stream));
+    return LCF_OK;
+}
 
 namespace {
 
@@ -2961,6 +3061,50 @@ extern "C" lcf_status lcf_profile_loglike_kernel(lcf_engine* e, int64_t n, const
     return LCF_OK;
 }
 
+namespace {
+// ---- memory that kernels POLL (row boards, mailboxes) is never handed back to the driver ---------------------------------
+// A board that was freed (hipFree) and whose address range the driver then gave to the next sampler's board left single
+// workgroups of the next launches reading the OLD contents of those addresses for as long as they polled -- rows that
+// every other workgroup (and the host) could see never arrived for them, 5 s waits, once also a stale row with a valid
+// tag (a wrong chain).  Reproduced deterministically by tools/debug/rows_mismatch.py once the inter-rank boards were
+// megabytes (freed uncached memory recycled into the next board); gone when such memory is not freed.  So: polled
+// memory goes back to a list of this process and is taken from there by the next sampler that needs the same size;
+// whoever takes it clears it (stale tags of an earlier life would be valid tags of the next) before anything reads it.
+struct PolledBlock { int dev; bool uncached; size_t bytes; void* p; };
+std::mutex g_polled_mutex;
+std::vector<PolledBlock> g_polled;
+
+void* polled_take(int dev, bool uncached, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_polled_mutex);
+    for (size_t k = 0; k < g_polled.size(); ++k)
+        if (g_polled[k].dev == dev && g_polled[k].uncached == uncached && g_polled[k].bytes == bytes) {
+            void* p = g_polled[k].p;
+            g_polled.erase(g_polled.begin() + (long)k);
+            return p;
+        }
+    return nullptr;
+}
+void polled_give(int dev, bool uncached, size_t bytes, void* p) {
+    std::lock_guard<std::mutex> lock(g_polled_mutex);
+    g_polled.push_back(PolledBlock{dev, uncached, bytes, p});
+}
+// `bytes` of polled memory on the current device, cleared (complete on return).
+lcf_status polled_alloc(int dev, bool uncached, size_t bytes, void** out) {
+    void* p = polled_take(dev, uncached, bytes);
+    if (!p) {
+        if (uncached)   // fine-grained device memory: peers' stores over the fabric and this rank's polls meet in memory
+            LCF_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+        else
+            LCF_HIP(hipMalloc(&p, bytes));
+    }
+    *out = p;
+    LCF_HIP(hipMemset(p, 0, bytes));        // tag 0: no version / generation (half-steps are numbered from 2)
+    LCF_HIP(hipDeviceSynchronize());
+    return LCF_OK;
+}
+
+}  // namespace
+
 // =================================================================================================================
 // sampler
 // =================================================================================================================
@@ -3002,6 +3146,7 @@ struct lcf_sampler {
     int last_kernel = -1;     // what the last run's half-steps were (lcf_sampler_last_run_kernel)
     long long last_launches = 0;   // launches of that kernel in the last run (lcf_sampler_last_run_launches)
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
+    size_t mailbox_cap = 0;
     void* board_mem = nullptr;               // this rank's row board (uncached device memory), see DevSampler
     std::vector<void*> board_opened;         // peers' boards mapped through IPC
     // One-launch runs write their final state into the other of two sets of state buffers (DevSampler::X_out ...):
@@ -3013,14 +3158,17 @@ struct lcf_sampler {
     int replay_split = 0, replay_store = 0;  // the last one-launch run, should it have to be repeated
     int64_t replay_first = 0, replay_steps = -1;
     void* run_board_mem = nullptr;           // the board of one-launch runs (k_solo_run): kRunRing versions, this GPU only
+    DevSampler* d_run_image = nullptr;       // the sampler as k_solo_run reads it (run_image)
+    DevSampler run_image_host{};
+    bool run_image_valid = false;
+    bool run_flip = false;                   // ds.X / LP / nacc name the SECOND set of state buffers
+    unsigned int run_arrivals = 0;           // workgroups of resident launches enqueued so far (the board's arrivals word)
     int run_capacity = -1;                   // workgroups of k_solo_run the device holds at once (-1: not asked yet)
     size_t run_board_bytes() const {
-        return (size_t)kRunRing * ds.n_walkers * (ds.n_dim + 2) * 2 * sizeof(unsigned long long) +
-               (size_t)kBoardTail * sizeof(unsigned int);
+        return board_rows_bytes(kRunRing, ds.n_walkers, ds.n_dim) + (size_t)kBoardTail * sizeof(unsigned int);
     }
     size_t board_bytes() const {
-        return (size_t)kRing * ds.n_walkers * (ds.n_dim + 2) * 2 * sizeof(unsigned long long) +
-               (size_t)kBoardTail * sizeof(unsigned int);
+        return board_rows_bytes(kRing, ds.n_walkers, ds.n_dim) + (size_t)kBoardTail * sizeof(unsigned int);
     }
     std::vector<void*> opened;               // peers' mailboxes mapped through IPC
     int peer_ranks = 0, peer_rank = 0;
@@ -3046,10 +3194,10 @@ struct lcf_sampler {
         if (ds.chain_lp) hipFree(ds.chain_lp);
         free_blocks();
         for (void* p : opened) hipIpcCloseMemHandle(p);
-        if (mailbox) hipFree(mailbox);
+        if (mailbox) polled_give(device, true, mailbox_cap, mailbox);
         for (void* p : board_opened) hipIpcCloseMemHandle(p);
-        if (board_mem) hipFree(board_mem);
-        if (run_board_mem) hipFree(run_board_mem);
+        if (board_mem) polled_give(device, true, board_bytes(), board_mem);
+        if (run_board_mem) polled_give(device, false, run_board_bytes(), run_board_mem);
         if (snap) hipHostFree(snap);
         if (d_perm_host) hipFree(d_perm_host);
         if (ev0) hipEventDestroy(ev0);
@@ -3400,25 +3548,44 @@ bool run_eligible(const lcf_sampler* s) {
             any_size);
 }
 
-struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; };
+struct RunBusy { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool used = false; bool enqueuing = false; };
 RunBusy g_run_busy[64];
 std::mutex g_run_mutex;
 
-// May a one-launch run go on stream `st` of device `dev` now?  (Yes unless another stream's is still in flight.)
+// May a one-launch run go on stream `st` of device `dev` now?  Yes unless another stream's is being enqueued (between its
+// claim and its release: the device counts as busy from the claim on, not only once the release has recorded the event)
+// or still in flight.
 bool run_claim(int dev, hipStream_t st) {
     if (dev < 0 || dev >= 64) return false;
     std::lock_guard<std::mutex> lock(g_run_mutex);
     RunBusy& b = g_run_busy[dev];
-    if (b.used && b.stream != st && hipEventQuery(b.ev) == hipErrorNotReady) return false;
+    if (b.stream != st) {
+        if (b.enqueuing) return false;
+        if (b.used) {
+            // (the event may have been recorded last on a stream that no longer exists -- its engine destroyed: whatever
+            // the query then says, nothing is in flight there; and what it says must not stay behind as the "last error")
+            const hipError_t q = hipEventQuery(b.ev);
+            (void)hipGetLastError();
+            if (q == hipErrorNotReady) return false;
+        }
+    }
     if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) return false;
     b.stream = st;
-    b.used = true;
+    b.enqueuing = true;
     return true;
 }
-void run_release(int dev, hipStream_t st) {   // behind the last launch of the run
+void run_release(int dev, hipStream_t st) {   // behind the last launch of the run (or on the way out of a failed enqueue)
     std::lock_guard<std::mutex> lock(g_run_mutex);
-    (void)hipEventRecord(g_run_busy[dev].ev, st);
+    RunBusy& b = g_run_busy[dev];
+    b.used = hipEventRecord(b.ev, st) == hipSuccess;
+    b.enqueuing = false;
 }
+struct RunClaim {   // releases on every path out of the enqueue
+    int dev;
+    hipStream_t st;
+    bool held;
+    ~RunClaim() { if (held) run_release(dev, st); }
+};
 
 template <class K>
 lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
@@ -3432,10 +3599,20 @@ lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
     return LCF_OK;
 }
 
-// Half-steps [rel, rel + n_hs) of the run, all inside the current block of draw records.
-lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
-    lcf_engine* e = s->e;
+// The sampler as k_solo_run reads it, in device memory (a constant-address-space pointer in the kernel): written when a
+// sampler's first one-launch run is enqueued and again only when something in it has changed (a longer chain).  The
+// two sets of state buffers keep their places in it -- X / LP / nacc = the set the sampler was created with -- and the
+// launch's flags say which of them holds the run's start state.
+lcf_status run_image(lcf_sampler* s, hipStream_t st, const DevSampler** out, int* flags) {
     DevSampler rs = s->ds;
+    const bool flip = s->run_flip;
+    rs.X = flip ? s->alt_X : s->ds.X;
+    rs.LP = flip ? s->alt_LP : s->ds.LP;
+    rs.nacc = flip ? s->alt_nacc : s->ds.nacc;
+    rs.X_out = flip ? s->ds.X : s->alt_X;
+    rs.LP_out = flip ? s->ds.LP : s->alt_LP;
+    rs.nacc_out = flip ? s->ds.nacc : s->alt_nacc;
+    rs.store_chain = rs.inline_finalize = rs.n_peers = 0;   // (per run: in the flags, or not read by this kernel)
     rs.board = static_cast<unsigned long long*>(s->run_board_mem);
     rs.peer_board[0] = rs.board;
     rs.n_board_ranks = 1;
@@ -3443,9 +3620,29 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
     rs.ring = kRunRing;
     rs.snap_out = reinterpret_cast<unsigned long long*>(s->snap);
     rs.snap_flags = s->snap_flags();
-    rs.X_out = s->alt_X;
-    rs.LP_out = s->alt_LP;
-    rs.nacc_out = s->alt_nacc;
+    if (!s->d_run_image) {
+        LCF_HIP(hipMalloc((void**)&s->d_run_image, sizeof(DevSampler)));
+        s->owned.push_back(s->d_run_image);
+        s->run_image_valid = false;
+    }
+    if (!s->run_image_valid || std::memcmp(&rs, &s->run_image_host, sizeof rs) != 0) {
+        // (by a kernel, in stream order behind the launches that read the old image: k_put_image)
+        hipLaunchKernelGGL(k_put_image<DevSampler>, dim3(1), dim3(64), 0, st, s->d_run_image, rs);
+        LCF_HIP(hipGetLastError());
+        std::memcpy(&s->run_image_host, &rs, sizeof rs);
+        s->run_image_valid = true;
+    }
+    *out = s->d_run_image;
+    *flags = (s->ds.store_chain ? kRunStoreChain : 0) | (flip ? kRunFlip : 0);
+    return LCF_OK;
+}
+
+// Half-steps [rel, rel + n_hs) of the run, all inside the current block of draw records.
+lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
+    lcf_engine* e = s->e;
+    const DevSampler* rs = nullptr;
+    int run_flags = 0;
+    if (lcf_status r = run_image(s, st, &rs, &run_flags)) return r;
     const DrawRec* draws = s->rows(rel);
     const size_t lds = solo_lds_bytes(e);
     const long long g_run0 = s->g_run0;
@@ -3459,8 +3656,10 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
         if (s->run_capacity < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");              \
         const int n_wg = std::min(s->ds.n_half, s->run_capacity);                                                     \
         const dim3 grid((unsigned)(test_missing && n_wg > 1 ? n_wg - 1 : n_wg));                                      \
+        s->run_arrivals += (unsigned int)n_wg;   /* (0 = "no check": skipped when the count wraps onto it) */          \
+        if (s->run_arrivals == 0u) s->run_arrivals = 1u;                                                              \
         hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
-                           g_run0, n_hs, state_from, n_wg);                                                           \
+                           g_run0, n_hs, state_from, n_wg, run_flags, s->run_arrivals);                               \
     } while (0)
 #define LCF_RUN4(ND, NP)                                                                                              \
     do {                                                                                                              \
@@ -3692,6 +3891,7 @@ lcf_status lcf_sampler_create(lcf_engine* e, int32_t n_walkers, uint64_t seed, d
     ds.key1 = (uint32_t)(seed >> 32);
     ds.a = a;
     ds.wait_ticks = peer_wait_ticks();
+    ds.resident_ticks = resident_wait_ticks();
     ds.ring = kRing;
     const size_t nw = n_walkers, nh = ds.n_half, nd = ds.n_dim;
     lcf_status st;
@@ -3740,8 +3940,11 @@ lcf_status lcf_sampler_set_state(lcf_sampler* s, const double* coords) {
     LCF_HIP(hipMemsetAsync(ds.err, 0, sizeof(int), e->stream));
     std::memset(s->snap_flags(), 0, 2 * kSnapFlags * sizeof(unsigned int));   // (after the device synchronisation above)
     if (s->run_board_mem)   // (the abort word and its diagnosis behind the rows of the one-launch runs' board)
-        LCF_HIP(hipMemsetAsync(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int), 0,
-                               5 * sizeof(unsigned int), e->stream));
+    {
+        LCF_HIP(hipMemsetAsync(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - kBoardClear * sizeof(unsigned int), 0,
+                               kBoardClear * sizeof(unsigned int), e->stream));
+        s->run_arrivals = 0;
+    }
     LCF_HIP(hipStreamSynchronize(e->stream));
     s->has_state = true;
     return LCF_OK;
@@ -3849,13 +4052,13 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
         // (an aborted multi-rank run leaves the ranks with different states -- a rank has committed its own walkers of
         // the half-step the others gave up on: the ensemble must be set again, on every rank, before the next run)
         const double sec = (double)s->ds.wait_ticks / 1e8;
-        unsigned int w[5] = {0, 0, 0, 0, 0};
+        unsigned int w[kBoardClear] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const bool run = s->last_kernel == LCF_KERNEL_RUN && s->run_board_mem;
         if (run)
-            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int),
+            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - kBoardClear * sizeof(unsigned int),
                       sizeof w, hipMemcpyDeviceToHost);
         else if (s->board_mem)
-            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - 5 * sizeof(unsigned int), sizeof w,
+            hipMemcpy(w, reinterpret_cast<unsigned char*>(s->board_mem) + s->board_bytes() - kBoardClear * sizeof(unsigned int), sizeof w,
                       hipMemcpyDeviceToHost);
         if (run && s->replay_steps >= 0 && s->replay_split != LCF_SPLIT_HOST) {
             // The launch's workgroups were not all resident (somebody else's resident kernel on this GPU): it gave up
@@ -3866,20 +4069,26 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
             std::swap(s->ds.X, s->alt_X);
             std::swap(s->ds.LP, s->alt_LP);
             std::swap(s->ds.nacc, s->alt_nacc);
+            s->run_flip = !s->run_flip;
             int sticky = 0;
             std::memcpy(&sticky, s->snap, sizeof(int));
             sticky &= 1;                                   // (a NaN of an earlier run stays reported)
             LCF_HIP(hipMemcpy(s->ds.err, &sticky, sizeof(int), hipMemcpyHostToDevice));
             std::memcpy(s->snap, &sticky, sizeof(int));
             std::memset(s->snap_flags(), 0, 2 * kSnapFlags * sizeof(unsigned int));
-            LCF_HIP(hipMemset(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - 5 * sizeof(unsigned int), 0,
-                              5 * sizeof(unsigned int)));
+            LCF_HIP(hipMemset(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - kBoardClear * sizeof(unsigned int), 0,
+                              kBoardClear * sizeof(unsigned int)));
+            s->run_arrivals = 0;
             static bool told = false;
             if (!told)
-                std::fprintf(stderr, "liblcf_hip: a one-launch run waited %.1f s for version %u of walker %u: its workgroups were "
+                std::fprintf(stderr, "liblcf_hip: a one-launch run waited %.2f s for version %u of walker %u: its workgroups were "
                              "not all resident (another resident kernel on this GPU?); the steps are repeated with a launch per "
                              "half-step, as are this sampler's later runs (LCF_NO_RUN_KERNEL=1 avoids the wait)\n",
-                             sec, w[2], w[3]);
+                             w[1] == 3 ? (double)s->ds.resident_ticks / 1e8 : sec, w[2], w[3]);
+            if (!told && std::getenv("LCF_TRACE_RUN"))
+                std::fprintf(stderr, "liblcf_hip: (what %u, column %u, workgroups started %u; the entry held {%08x tag %u | %08x tag %u}; host: "
+                             "%d walkers, board %08x)\n", w[1], w[4], w[5], w[6], w[7], w[8], w[9], s->ds.n_walkers,
+                             (unsigned int)(unsigned long long)s->run_board_mem);
             told = true;
             s->run_off = true;
             s->spec_first = -1;
@@ -4069,8 +4278,8 @@ lcf_status mailbox_alloc(lcf_sampler* s) {
     if (s->mailbox) return LCF_OK;
     LCF_HIP(hipSetDevice(s->e->device));
     // uncached (fine-grained) device memory: peers' stores over the fabric and this rank's polls meet in memory
-    LCF_HIP(hipExtMallocWithFlags((void**)&s->mailbox, mailbox_bytes(s), hipDeviceMallocUncached));
-    LCF_HIP(hipMemset(s->mailbox, 0, mailbox_bytes(s)));  // tag 0: no generation (half-steps are numbered from 2)
+    s->mailbox_cap = mailbox_bytes(s);
+    if (lcf_status st = polled_alloc(s->e->device, true, s->mailbox_cap, (void**)&s->mailbox)) return st;
     return LCF_OK;
 }
 }  // namespace
@@ -4156,8 +4365,7 @@ lcf_status board_alloc(lcf_sampler* s) {
     if (s->board_mem) return LCF_OK;
     LCF_HIP(hipSetDevice(s->e->device));
     // uncached (fine-grained) device memory: peers' stores over the fabric and this rank's polls meet in memory
-    LCF_HIP(hipExtMallocWithFlags(&s->board_mem, s->board_bytes(), hipDeviceMallocUncached));
-    LCF_HIP(hipMemset(s->board_mem, 0, s->board_bytes()));  // tag 0: no version (half-steps are numbered from 2)
+    if (lcf_status st = polled_alloc(s->e->device, true, s->board_bytes(), &s->board_mem)) return st;
     s->ds.board = static_cast<unsigned long long*>(s->board_mem);
     return LCF_OK;
 }
@@ -4263,6 +4471,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
                                  const int32_t* perm, int32_t store_chain) {
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     const bool one_launch = run_eligible(s) && n_steps > 0 && run_claim(s->e->device, s->e->stream);
+    RunClaim claim{s->e->device, s->e->stream, one_launch};
     if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain,
                                       !solo_eligible(s) || run_eligible(s))) return st;
     hipStream_t st = s->e->stream;
@@ -4270,8 +4479,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     LCF_HIP(hipEventRecord(s->ev0, st));
     if (one_launch) {   // the workgroups stay for a block of half-steps and hand each other rows (k_solo_run)
         if (!s->run_board_mem) {
-            LCF_HIP(hipMalloc(&s->run_board_mem, s->run_board_bytes()));
-            LCF_HIP(hipMemsetAsync(s->run_board_mem, 0, s->run_board_bytes(), st));   // tag 0: no version
+            if (lcf_status r = polled_alloc(s->e->device, false, s->run_board_bytes(), &s->run_board_mem)) return r;
             const size_t nw = s->ds.n_walkers;
             if (lcf_status r = dalloc(&s->alt_X, nw * s->ds.n_dim, s->owned)) return r;
             if (lcf_status r = dalloc(&s->alt_LP, nw, s->owned)) return r;
@@ -4297,7 +4505,9 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
         std::swap(s->ds.X, s->alt_X);          // the state behind this run is in the other set now
         std::swap(s->ds.LP, s->alt_LP);
         std::swap(s->ds.nacc, s->alt_nacc);
+        s->run_flip = !s->run_flip;
         LCF_HIP(hipEventRecord(s->ev1, st));
+        claim.held = false;
         run_release(s->e->device, st);
         // (the last step wrote the snapshot with the state: no snapshot kernel; the caller waits for this event)
         LCF_HIP(hipEventRecord(s->ev_snap, st));
@@ -4549,6 +4759,18 @@ double lcf_sampler_last_run_ms(const lcf_sampler* s) { return s ? s->last_ms : 0
 
 }  // extern "C"
 
+// (diagnostic, not in lcf.h) a copy of the board of the sampler's one-launch runs: rows, then the tail words
+extern "C" long long lcf_debug_read_run_board(lcf_sampler* s, void* out, long long max_bytes) {
+    if (!s || !s->run_board_mem) return -1;
+    const long long n = std::min<long long>(max_bytes, (long long)s->run_board_bytes());
+    if (hipMemcpy(out, s->run_board_mem, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    return n;
+}
+#ifdef LCF_PROGRESS
+extern "C" int lcf_debug_read_progress(unsigned int* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_progress), sizeof(unsigned int) * 64 * 16);
+}
+#endif
 #ifdef LCF_STAMPS
 extern "C" int lcf_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);

@@ -44,6 +44,8 @@ def test_config1_chain_at_the_benchmark_shape():
     x0 = bench.initial_walkers(1024)
     s = EnsembleSampler(1024, 5, eng, seed=bench.SEED)
     s.run_mcmc(x0, 6)
+    # (the kernel the headline times: resident workgroups -- not the launch-by-launch repeat of a launch that gave up)
+    assert s._native.last_run_kernel() == 'run'
     ref, ref_lp, ref_acc = O.stretch_move_run(log_posterior, x0, 6, bench.SEED)
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
     assert np.array_equal(np.round(s.acceptance_fraction * 6).astype(int), ref_acc) and ref_acc.sum() > 500

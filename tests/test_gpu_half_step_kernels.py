@@ -132,15 +132,20 @@ def test_two_runs_in_flight_keep_one_resident_launch_per_device():
 def test_a_resident_launch_that_cannot_finish_is_repeated_launch_by_launch(monkeypatch, capfd):
     """k_solo_run's workgroups wait for each other, so all of them must be on the device at once.  When they are not
     (LCF_RUN_TEST_MISSING: the last workgroup is never launched -- as when another process's resident kernel holds the
-    compute units), the waits end after LCF_PEER_WAIT_S, the launch has not touched the state it started from, and the
-    library repeats the same steps with a launch per half-step: same chain, same counts, one line on stderr, and the
-    sampler stays with k_solo afterwards."""
+    compute units), a workgroup that has waited LCF_RESIDENT_WAIT_S (50 ms) for a row looks at the count of the launch's
+    workgroups that have started, finds one missing and gives up -- long before LCF_PEER_WAIT_S (5 s, the bound for a row
+    of a launch that IS complete); the launch has not touched the state it started from, and the library repeats the
+    same steps with a launch per half-step: same chain, same counts, one line on stderr, and the sampler stays with
+    k_solo afterwards."""
+    import time
     pb, eng = _multiband()
     x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(6).standard_normal((40, 5)))
     ref = _run(eng, 40, 17, x0, 12, 'solo')
     monkeypatch.setenv('LCF_RUN_TEST_MISSING', '1')
-    monkeypatch.setenv('LCF_PEER_WAIT_S', '0.3')
+    monkeypatch.delenv('LCF_PEER_WAIT_S', raising=False)
+    t0 = time.perf_counter()
     got = _run(eng, 40, 17, x0, 12, 'auto')
+    assert time.perf_counter() - t0 < 0.5          # (sampler, state, the launch that gives up, the repeat, the chain)
     assert got[0] == 'run' and got[4].last_run_kernel() == 'solo'
     assert 'repeated with a launch per half-step' in capfd.readouterr().err
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
@@ -343,7 +348,7 @@ def test_peer_mailboxes_between_processes(ranks):
 
 
 def test_collective_none_probes_and_picks_a_driver_between_processes():
-    """EnsembleSampler(collective=None) with two real processes: the first run probes rows / peers / all-gather (the ranks
+    """EnsembleSampler(collective='auto') with two real processes: the first run probes rows / peers / all-gather (the ranks
     agree on the fastest one that works), the chain is the single-GPU chain whichever won, and a second sampler of the
     same process group reuses the choice without probing again."""
     import json

@@ -7,7 +7,7 @@ end with the chain of the single-GPU run, bit for bit.
     python tools/peer_ranks_check.py [n_ranks=2] [n_walkers=64] [n_steps=12] [peers|rows|auto]
 
 `rows`: the same check for the row boards (every rank moves its share of the walkers itself and posts their rows).
-`auto`: EnsembleSampler(collective=None) -- the sampler probes the three drivers on its first run (the ranks agree on the
+`auto`: EnsembleSampler(collective='auto') -- the sampler probes the three drivers on its first run (the ranks agree on the
 fastest one that works) and runs with it; the line says which.
 
 Started without a launcher it spawns the ranks itself (fresh processes; the parent never touches the GPU); rank 0
@@ -58,13 +58,13 @@ def main():
     ref = EnsembleSampler(n_walkers, 5, eng, seed=2024, group=None, collective='allgather')
     ref._distributed = lambda: False          # the single-GPU run of the same ensemble
     ref.run_mcmc(x0, n_steps)
-    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective=None if driver == 'auto' else driver)
+    s = EnsembleSampler(n_walkers, 5, eng, seed=2024, collective=driver)
     s.run_mcmc(x0, n_steps // 2)
     probe = s.collective_probe
     if driver == 'auto':
         assert s.collective in ('rows', 'peers', 'allgather') and probe is not None and probe['selected'] == s.collective
         driver = s.collective
-        t = EnsembleSampler(n_walkers, 5, eng, seed=1, collective=None)     # a second sampler of the group: no new probe
+        t = EnsembleSampler(n_walkers, 5, eng, seed=1, collective='auto')   # a second sampler of the group: no new probe
         t.run_mcmc(x0, 2)
         assert t.collective == s.collective and t.collective_probe is None
     s.run_mcmc(None, n_steps - n_steps // 2)   # a second run: generations continue, the barrier between runs
