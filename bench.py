@@ -108,6 +108,8 @@ def parse_args(argv=None):
                          'bookkeeping; allgather: the same with one RCCL all-gather per half-step.  auto (default): all '
                          'three are tried for a few untimed steps -- a driver that fails, or whose ranks end in different '
                          'states, is out -- and the fastest one runs the timed steps; the line says which and why')
+    ap.add_argument('--end-to-end-child', action='store_true',
+                    help='(internal) a fresh process times lightcurve_mcmc() calls from call to chain and prints them')
     ap.add_argument('--launch-check', action='store_true',
                     help='only start the ranks, let them find each other (gloo) and print what they saw')
     return ap.parse_args(argv)
@@ -211,10 +213,15 @@ def max_over_ranks(dist, elapsed):
     return float(tmax.item())
 
 
-def timed_run(sampler, dist, warmup, steps, x0, store=True):
+def timed_run(sampler, dist, warmup, steps, x0, store=True, reps=None):
     """W untimed warm-up steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the maximum
     over the ranks.  `store`: the timed run keeps its chain (every walker's position and log-posterior after every step,
-    in HBM), as the reference's sampling run does (fitting.py:144-148: emcee's default)."""
+    in HBM), as the reference's sampling run does (fitting.py:144-148: emcee's default).
+
+    The timed region is REPEATED (`reps`, default LCF_BENCH_REPS or 5: each repetition is a run of exactly `steps` steps
+    that continues the previous one, bracketed the same way) and the MEDIAN repetition is what the line reports: at the
+    driver's 20 steps one repetition is a single 0.3 ms sample.  Returns (seconds of the median repetition, all
+    repetitions' seconds, device milliseconds of the median repetition on this rank)."""
     import torch
 
     def barrier():
@@ -224,23 +231,37 @@ def timed_run(sampler, dist, warmup, steps, x0, store=True):
             torch.cuda.synchronize()
 
     import gc
+    reps = reps or max(1, int(os.environ.get('LCF_BENCH_REPS', '5')))
     was_enabled = gc.isenabled()
     if was_enabled:      # As timeit does: a generation-2 collection of the interpreter (40-80 ms when it strikes, seen
         gc.collect()     # once in eight 0.6 ms runs, tools/debug/short_run_breakdown.py) is not the sampler's time.
         gc.disable()     # Collected BEFORE the warm-up (the caller may have done it even earlier, see quiet_interpreter):
+    times, device = [], []
     try:                 # the timed steps must follow busy work without a pause in which the device clocks down.
         if store:
             sampler.reserve_chain(steps)              # (the chain's device memory: allocated with everything else)
         sampler.run_mcmc(x0, warmup, store=False)     # untimed warm-up (also allocates everything)
-        barrier()
-        t0 = time.perf_counter()
-        sampler.run_mcmc(None, steps, store=store)    # returns after the device has finished
-        barrier()
-        elapsed = time.perf_counter() - t0
+        for rep in range(reps):
+            if rep:
+                sampler.reset()                       # (untimed: the previous repetition's chain is dropped, not downloaded)
+            barrier()
+            t0 = time.perf_counter()
+            sampler.run_mcmc(None, steps, store=store)    # returns after the device has finished
+            barrier()
+            times.append(max_over_ranks(dist, time.perf_counter() - t0))
+            device.append(sampler.last_run_ms)
     finally:
         if was_enabled:
             gc.enable()
-    return max_over_ranks(dist, elapsed)
+    mid = int(np.argsort(times)[(len(times) - 1) // 2])    # (an actual repetition: the lower median of an even count)
+    return times[mid], times, device[mid]
+
+
+def timed_region_block(times, steps, ran):
+    """What the timed region consisted of: its repetitions (value = the median one) and what executed the half-steps."""
+    return {'repetitions': len(times), 'steps_per_repetition': steps, 'seconds': [float(t) for t in times],
+            'reported': 'median repetition', 'spread': float((max(times) - min(times)) / np.median(times)),
+            'half_step_kernel': ran['kernel'], 'launches_per_repetition': ran['launches']}
 
 
 def quiet_interpreter():
@@ -271,9 +292,14 @@ def collective_info(sampler, dist, world):
     n_half = (sampler.nwalkers + 1) // 2
     rows = sampler._native.rows_ptr()[1]
     if sampler.collective == 'rows' and sampler._boards:
-        return {'driver': 'row boards: every rank moves its share of the walkers with k_solo and stores their new rows '
-                          "(position, log-posterior, acceptance count) straight into all ranks' boards (IPC-mapped device "
-                          'memory); no collective, no launch between half-steps, nothing replicated',
+        resident = sampler._native.last_run_kernel() == 'run'
+        return {'driver': 'row boards: every rank moves its share of the walkers '
+                          + ('with RESIDENT workgroups (k_solo_run<..., RANKS>: one launch per block of up to 32 steps, the '
+                             "ranks' drift bounded by one progress word per rank and launch) " if resident else
+                             'with a k_solo launch per half-step ')
+                          + "and stores their new rows (position, log-posterior, acceptance count) straight into all ranks' "
+                            'boards (IPC-mapped device memory); no collective, nothing replicated',
+                'resident_workgroups': resident,
                 'rccl_comm_ranks': None, 'group_ranks': dist.get_world_size(), 'allgather_us': None,
                 'payload_bytes_per_rank': 16 * (sampler.ndim + 2) * n_half // world}
     if sampler.collective == 'peers' and sampler._peers:
@@ -400,11 +426,10 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
 def quads_per_evaluation(engine, truth):
     """(quads of samples one likelihood evaluation walks, points on the interpolated path) at the parameters `truth`:
     the table level is chosen per point from its temperature."""
-    from lightcurve_fitting_amd.filters import INTERP_TMAX
     T, _ = engine.temperature_radius(np.asarray(truth, dtype=float))
     variant = getattr(engine, '_variant', 3)
     tabs, f = engine.tables, engine.filt_idx
-    interp = (variant == 3) & (T[0] >= tabs.itmin[f]) & (T[0] <= INTERP_TMAX)
+    interp = (variant == 3) & (T[0] >= tabs.itmin[f]) & (T[0] <= tabs.itmax)
     n = np.where(interp, 0, tabs.samples_at(f, T[0], variant >= 2))
     return float(np.sum(n) / 4.), int(np.sum(interp))
 
@@ -523,13 +548,20 @@ def run_mcmc(args):
                                      x0, args)
     kern_ms, used, hs_per_launch = (half_step_kernel_ms(engine, n_walkers // world, x0, SEED + 7)
                                     if rank == 0 or world > 1 else (None, None, None))
-    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)       # the chain is stored, as the reference's run does
+    elapsed, elapsed_all, device_ms = timed_run(sampler, dist, args.warmup, args.steps, x0)   # the chain is stored, as the reference's run does
     value = n_walkers * args.steps / elapsed
-    device_ms = sampler.last_run_ms
+    ran = {'kernel': sampler._native.last_run_kernel(), 'launches': sampler._native.last_run_launches()}
+    measured_in_the_run = False
+    if world > 1 and getattr(sampler, 'collective', None) == 'rows' and ran['kernel'] == 'run' and ran['launches'] > 0:
+        # The kernel the selected multi-rank driver actually launched: this rank's resident launches of the timed run
+        # itself (HIP events around the whole run on the rank's stream / its launches: the row collection behind every
+        # launch and the two small kernels around the run are inside -- an upper bound of the launch alone).
+        kern_ms, used, hs_per_launch = device_ms / ran['launches'], 'run', 2. * args.steps / ran['launches']
+        measured_in_the_run = True
     t0 = time.perf_counter()
     chain_shape = sampler.get_chain().shape                                # 48 bytes per walker and step over PCIe
     download_s = time.perf_counter() - t0
-    elapsed_nochain = timed_run(sampler, dist, args.warmup, args.steps, None, store=False)
+    elapsed_nochain, _, _ = timed_run(sampler, dist, args.warmup, args.steps, None, store=False)
     coll = collective_info(sampler, dist, world)
     if coll is not None:
         coll['probe'] = probe
@@ -551,9 +583,13 @@ def run_mcmc(args):
                               interp=(n_interp, N_EPOCHS) if n_interp else None)
         roof['half_steps_per_launch'] = hs_per_launch
         roof['kernel_ms_per_half_step'] = kern_ms / hs_per_launch
-        if world > 1:
-            roof['kernel'] += (" [one rank's share as a single-GPU run: the reference point of the multi-rank drivers, "
-                               'which launch k_solo<BOARD> / k_fused per half-step]')
+        if world > 1 and measured_in_the_run:
+            roof['kernel'] = ('k_solo_run<5,1,true,2,ShockCooling,RANKS> (this rank\'s resident workgroups, one per proposal of '
+                              'its share: %d half-steps per launch; rows from its own board, commits posted on every rank\'s '
+                              'board) -- timed in the run itself, row collection included' % round(hs_per_launch))
+        elif world > 1:
+            roof['kernel'] += (" [one rank's share as a single-GPU run: the reference point of the multi-rank drivers that "
+                               'launch k_solo<BOARD> / k_fused per half-step]')
         out = {
             'metric': 'walker-steps/sec (emcee ensemble)', 'value': value, 'unit': 'walker-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -566,6 +602,7 @@ def run_mcmc(args):
                        'band_sum_variant': args.variant,
                        'parallelism': f'walker-sharded x{world}' if world > 1 else 'single GPU'},
             'roofline': roof, 'collective': coll,
+            'timed_region': timed_region_block(elapsed_all, args.steps, ran),
             'device_ms_per_step': device_ms / args.steps if world == 1 else None,
             'chain': {'stored': True, 'shape': list(chain_shape),
                       'note': 'value is the run that keeps its chain in HBM (the reference: emcee stores every step, '
@@ -581,10 +618,76 @@ def run_mcmc(args):
                 out['cpu_baseline_c'] = cpu_baseline_c(lc)
             except Exception as exc:  # noqa: BLE001 - the extra reference point must never break the bench line
                 out['cpu_baseline_c'] = {'error': repr(exc)}
+        if world == 1 and os.environ.get('LCF_BENCH_NO_E2E') != '1':
+            out['end_to_end'] = end_to_end_block(lc)
         emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end_child(args):
+    """In a FRESH process: what a user's `lightcurve_mcmc(lc, model, priors, ..., nwalkers=1024, nsteps=2000,
+    nsteps_burnin=1000)` costs from the call to the chain complete in HBM (fitting.py:16-168 is the unit a user runs; the
+    timed region of the headline is its two run_mcmc calls only).  Three calls: the first one of the process (cold: HIP
+    and the library's code objects are loaded inside it), a second one on another light curve (warm process, everything
+    of the fit itself new: tables, engine, sampler), a third one on the second light curve again (its engine is still
+    the model's).  Prints one JSON object."""
+    t_start = time.perf_counter()
+    import torch  # noqa: F401  (what `import lightcurve_fitting_amd` of a user's script costs most of; no GPU call yet)
+    from lightcurve_fitting_amd import fitting
+    from lightcurve_fitting_amd import models as M
+    import_s = time.perf_counter() - t_start
+    data = np.load(os.environ['LCF_E2E_LC'])     # the headline's light curve, made by the parent: nothing here has
+    lc0 = {'MJD': data['MJD'], 'filter': [str(f) for f in data['filter']], 'lum': data['lum'], 'dlum': data['dlum']}
+    priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]   # touched the GPU before the first call
+    out = {'import_s': import_s, 'walkers': WALKERS_PER_GPU, 'steps': 2000, 'burn_in_steps': 1000, 'calls': []}
+    lo, hi = TRUTH * 0.8, TRUTH * 1.2
+    lo[4], hi[4] = 0., 0.2
+    model, lc, sampler = None, None, None
+    for k, label in enumerate(['cold process: first call (HIP, the library and its code objects are loaded inside it)',
+                               'warm process: new model, new light curve, new engine',
+                               'warm process: same light curve again (engine kept by the model)']):
+        if k < 2:
+            model = M.ShockCooling(redshift=0., n=1.5)
+            lc = dict(lc0, lum=lc0['lum'] * (1. + 0.001 * k))    # (other photometry: nothing of the first call is reused)
+        sampler = None                                           # (the previous call's sampler and its chain go now)
+        np.random.seed(SEED + k)
+        t0 = time.perf_counter()
+        sampler = fitting.lightcurve_mcmc(lc, model, priors=priors, p_lo=lo, p_up=hi, nwalkers=WALKERS_PER_GPU,
+                                          nsteps=2000, nsteps_burnin=1000, seed=SEED + k)
+        wall = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        shape = sampler.flatchain.shape
+        out['calls'].append({'what': label, 'call_to_chain_in_hbm_s': wall, 'phases_s': sampler.timings,
+                             'chain_to_host_s': time.perf_counter() - t1, 'flatchain_shape': list(shape),
+                             'half_step_kernel': sampler._native.last_run_kernel(),
+                             'walker_steps_per_s_of_the_whole_call': WALKERS_PER_GPU * 3000 / wall})
+    print(json.dumps(out), flush=True)
+
+
+def end_to_end_block(lc):
+    """Runs end_to_end_child in a fresh interpreter (the GPU is shared with this idle process) and returns its object."""
+    import tempfile
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+        tmp = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
+        tmp.close()
+        np.savez(tmp.name, MJD=lc['MJD'], filter=np.array(lc['filter']), lum=lc['lum'], dlum=lc['dlum'])
+        env['LCF_E2E_LC'] = tmp.name
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), '--end-to-end-child'], env=env, capture_output=True,
+                             text=True, timeout=300)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+        if res.returncode != 0 or not lines:
+            return {'error': (res.stderr or res.stdout)[-400:]}
+        os.unlink(tmp.name)
+        doc = json.loads(lines[-1])
+        doc['note'] = ('lightcurve_mcmc(lc, model, priors, nwalkers=1024, nsteps=2000, nsteps_burnin=1000) in a fresh process, '
+                       'wall time from the call to the chain complete in HBM; phases: checks / engine (band tables on the '
+                       'host + device engine) / sampler / burn-in / run')
+        return doc
+    except Exception as exc:  # noqa: BLE001 - an extra block must never break the bench line
+        return {'error': repr(exc)}
 
 
 def build_companion(device):
@@ -646,8 +749,9 @@ def run_companion(args):
                                      args)
     kern_ms, used, hs_per_launch = (half_step_kernel_ms(engine, nw // world, x0, SEED + 7, reps=192)
                                     if rank == 0 or world > 1 else (None, None, None))
-    elapsed = timed_run(sampler, dist, args.warmup, args.steps, x0)
+    elapsed, elapsed_all, device_ms = timed_run(sampler, dist, args.warmup, args.steps, x0)
     value = nw * args.steps / elapsed
+    ran = {'kernel': sampler._native.last_run_kernel(), 'launches': sampler._native.last_run_launches()}
     coll = collective_info(sampler, dist, world)
     if coll is not None:
         coll['probe'] = probe
@@ -682,7 +786,8 @@ def run_companion(args):
                           'walkers': nw, 'points': 8000, 'planck_samples_per_eval': full,
                           'planck_samples_executed_per_eval': 4 * quads, 'points_interpolated_per_eval': n_interp},
                'roofline': roof, 'collective': coll,
-               'device_ms_per_step': sampler.last_run_ms / args.steps if world == 1 else None}
+               'timed_region': timed_region_block(elapsed_all, args.steps, ran),
+               'device_ms_per_step': device_ms / args.steps if world == 1 else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline_companion(lc, lum0)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
@@ -910,6 +1015,8 @@ def main():
         # no launcher: start the ranks here, BEFORE anything in this process initialises the GPU (torch is not even
         # imported in the parent)
         sys.exit(spawn_ranks(args.gpus))
+    if args.end_to_end_child:
+        return end_to_end_child(args)
     keep_stdout_for_the_result()
     if args.launch_check:
         return launch_check(args)

@@ -1584,7 +1584,7 @@ __device__ inline unsigned int board_tag(long long G, int age, long long g_run0)
 __global__ void k_board_init(const DevSampler sm, unsigned int tag) {
     const int cols = sm.n_dim + 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 5) __hip_atomic_store(board_progress(sm.board, sm) + kMaxPeers + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (idx < kBoardClear) __hip_atomic_store(board_progress(sm.board, sm) + kMaxPeers + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (idx >= (long long)sm.n_walkers * cols) return;
     const int wid = (int)(idx / cols), col = (int)(idx % cols);
     const double v = col < sm.n_dim ? sm.X[(size_t)wid * sm.n_dim + col] : col == sm.n_dim ? sm.LP[wid] : (double)sm.nacc[wid];
@@ -1741,6 +1741,8 @@ constexpr int kSoloScratch = kNCoef + 2 + 2 * (kMaxDim + (kMaxDim & 1));  // dou
 // NPARTS = 8: three or four parts again, but FOUR groups of 256 threads, one part each at the same time (1024 threads):
 // for launches of at most one workgroup per CU -- a rank's share of a strongly scaled ensemble, configs[2] on 8 GPUs:
 // 256 proposals -- where a second workgroup to overlap with does not exist and the parts of one proposal can.
+// BOARD = 3: the same between ranks (k_solo_run<..., RANKS>): rows from this rank's board, the commit posts on every rank's;
+// state and chain are collected from the board behind the launch (k_board_collect), nothing else is written here.
 // BOARD = 2: one half-step of a ONE-LAUNCH run (k_solo_run below): rows from / to this GPU's own board, the chain written
 // here; `first`: the workgroup's first half-step of the launch (tables staged, first columns fetched: both stay).
 // Returns true when the run is aborted (uniform over the workgroup).
@@ -1788,12 +1790,12 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         // the one wave that everybody behind it waits for goes first (5.75 against 6.03 us per half-step; with a launch
         // per half-step both workgroups are in their heads at once and the priority only starves the staging waves:
         // 8.06 against 7.71 us)
-        if (BOARD == 2) __builtin_amdgcn_s_setprio(3);
+        if (BOARD >= 2) __builtin_amdgcn_s_setprio(3);
         HeadRows<ND> rows;
         head_fetch<ND, BOARD>(pb, sm, dr, tid, rows, G, g_run0, arrive_goal);
         if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
         proposal_head<ND, BOARD, MODEL>(pb, sm, dr, tid, sc, sq, sx, rows);
-        if (BOARD == 2) __builtin_amdgcn_s_setprio(0);
+        if (BOARD >= 2) __builtin_amdgcn_s_setprio(0);
     } else {
         if (LCF_HEAD_START > 0) __builtin_amdgcn_s_sleep(LCF_HEAD_START);
         if (kFetch && first) fetch_column<VARIANT, MODEL>(pb, tid / kBlock, tid % kBlock, first_col);
@@ -1807,7 +1809,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         }
         if (!reddened && first) stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid - 64, kThreads - 64);
         LCF_STAMP(1, 11);
-        if (BOARD == 2 && tid == 64) sctl[0] = board_aborted<true>(sm) ? 1 : 0;   // (in the shadow of the head)
+        if (BOARD >= 2 && tid == 64) sctl[0] = board_aborted<BOARD == 2>(sm) ? 1 : 0;   // (in the shadow of the head)
         if (BOARD == 1 && tid < 128) {
             // In the shadow of the head: has every rank finished half-step G - 2 (lane = rank)?  has this rank given up?
             const int lane = tid - 64;
@@ -1910,7 +1912,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         // rank's board; this rank's X / LP / counts follow for its own walkers (the others' come from the board when
         // the run ends, and the chain is written from the board)
         if (tid >= 64) return false;
-        if (BOARD == 2) __builtin_amdgcn_s_setprio(3);   // (the row's readers wait for this)
+        if (BOARD >= 2) __builtin_amdgcn_s_setprio(3);   // (the row's readers wait for this)
         double nlp = -INFINITY;
         if (!excluded) {
             double sum = pb.use_sigma ? 0. : pb.log_norm_const;
@@ -1931,7 +1933,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             }
             // (a one-launch run writes the state in its last step only: every walker moves exactly once there, while two
             // moves of a walker in one launch come from different workgroups, and whose store reaches memory last is open)
-            if (BOARD != 2 || write_state) {
+            if (BOARD == 1 || (BOARD == 2 && write_state)) {
                 // (one-launch runs: into the set of state buffers the run did NOT start from -- kRunFlip says which)
                 const bool to_out = BOARD == 2 && !(run_flags & kRunFlip);
                 double* X = to_out ? sm.X_out : sm.X;
@@ -1959,7 +1961,7 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             atomicOr(sm.err, 1);
             if (BOARD == 2 && sm.snap_flags) sm.snap_flags[blockIdx.x & (kSnapFlags - 1)] = 1u;
         }
-        if (BOARD == 2) __builtin_amdgcn_s_setprio(0);
+        if (BOARD >= 2) __builtin_amdgcn_s_setprio(0);
         LCF_STAMP(0, 10);
         return false;
     }
@@ -2019,11 +2021,19 @@ void k_solo(const DevProblem* __restrict__ pbp, const DevSampler sm, long long r
 // Every wait is for a row of an EARLIER half-step, so the launch makes progress as long as all its workgroups are
 // resident at once: the host launches no more than the device holds.  The ring keeps more versions than a launch has
 // half-steps (DevSampler::ring), so no workgroup can overrun a version another one still waits for.
-template <int ND, int VARIANT, bool THERM, int NPARTS, int MODEL>
+// RANKS: the launch of ONE RANK of a row-board run.  The rank's workgroups take its slots [slot_lo, slot_lo + n_slots) of
+// every half-step of the launch; rows come from the rank's own board, every commit goes to the boards of all ranks
+// (BOARD = 3).  What bounds the drift between ranks is a word per rank and launch instead of one per half-step: the
+// launch's first workgroup posts "this rank has reached half-step G0" on every board -- stream order proves that all the
+// rank's earlier launches and their row collections are complete -- and no workgroup starts before every rank has
+// reached `need_progress` (the first half-step of the launch before the previous one; 0: nothing to wait for).  With
+// at most kRunSpan half-steps per launch, anything a rank still reads is then less than kRing versions behind
+// anything another rank writes.
+template <int ND, int VARIANT, bool THERM, int NPARTS, int MODEL, bool RANKS = false>
 __global__ __launch_bounds__(kBlock * (NPARTS == 8 ? 4 : 2), LCF_WAVES)
 void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler* __restrict__ smp, long long rel0,
                 const DrawRec* __restrict__ draws0, long long g_run0, int n_hs, long long state_from, int n_wg, int run_flags,
-                unsigned int arrive_goal) {
+                unsigned int arrive_goal, int slot_lo, int n_slots, long long need_progress) {
     // (n_wg = gridDim.x, except in the test of a launch whose workgroups are not all there: LCF_RUN_TEST_MISSING)
     extern __shared__ __align__(16) unsigned char smem[];
     // (a lane's first column: fetched by the launch's first half-step and kept -- 26 registers, a few of them spilled;
@@ -2037,12 +2047,46 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler* __restrict
     typedef const DevSampler __attribute__((address_space(4)))* SamplerPtr;
     const DevProblem& pb = *(const DevProblem*)(ProblemPtr)pbp;
     const DevSampler& sm = *(const DevSampler*)(SamplerPtr)smp;
+    constexpr int kBoard = RANKS ? 3 : 2;
     bool first = true;
     // "this workgroup has started": what a workgroup that waits unusually long for a row looks at (board_take)
     if (threadIdx.x == 0) __hip_atomic_fetch_add(board_arrivals(sm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (rel0 == 0) {
+    if (RANKS) {
+        __shared__ int s_abort;
+        if (blockIdx.x == 0 && threadIdx.x < sm.n_board_ranks)
+            __hip_atomic_store(board_progress(sm.peer_board[threadIdx.x], sm) + sm.board_rank, (unsigned int)(g_run0 + rel0),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x < 64) {
+            bool abort = false;
+            if (need_progress > 0) {
+                const int lane = threadIdx.x;
+                const unsigned int* progress = board_progress(sm.board, sm);
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    bool ok = true;
+                    if (lane < sm.n_board_ranks)
+                        ok = (int)(__hip_atomic_load(progress + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
+                                   (unsigned int)need_progress) >= 0;
+                    abort = board_aborted(sm);
+                    if (__all(ok) || abort) break;
+                    if (wall_clock64() - t0 > sm.wait_ticks) {
+                        board_abort(sm, 2u, (unsigned int)(g_run0 + rel0), (unsigned int)__builtin_ctzll(~__ballot(ok)),
+                                    (unsigned int)need_progress);
+                        abort = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (threadIdx.x == 0) s_abort = abort ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_abort != 0) return;
+    }
+    if (!RANKS && rel0 == 0) {
         // The run's first launch: the state in front of it is version g_run0 of every row (what a draw record's age
         // points at until the walker has moved in this run).  Whoever needs a row polls for it: no barrier behind this.
+        // (RANKS: every rank holds the whole state and has posted it on its OWN board: k_board_init, in front of the run.)
         const int nd = ND > 0 ? ND : sm.n_dim;
         const int col = threadIdx.x & 31;   // (n_dim + 2 <= kMaxDim + 2 columns)
         const bool flip = (run_flags & kRunFlip) != 0;
@@ -2056,19 +2100,20 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler* __restrict
                 board_post<true>(sm.board, sm, (unsigned int)g_run0, w, col, v);
             }
     }
+    const int slot_end = slot_lo + n_slots;
 #pragma unroll 1
     for (int h = 0; h < n_hs; ++h) {
         const DrawRec* draws = draws0 + (size_t)h * sm.n_half;
 #pragma unroll 1
-        for (int i = blockIdx.x; i < sm.n_half; i += n_wg) {
+        for (int i = slot_lo + blockIdx.x; i < slot_end; i += n_wg) {
             if (draws[i].wid < 0) continue;   // (uniform) an odd ensemble's smaller colour leaves its last slot empty
             // the record this workgroup needs next: its next slot of this half-step, else its first of the next one
-            const bool more = i + n_wg < sm.n_half;
-            const DrawRec* hint = more ? draws + n_wg : h + 1 < n_hs ? draws + sm.n_half + ((int)blockIdx.x - i) : nullptr;
+            const bool more = i + n_wg < slot_end;
+            const DrawRec* hint = more ? draws + n_wg : h + 1 < n_hs ? draws + sm.n_half + (slot_lo + (int)blockIdx.x - i) : nullptr;
             const int tid = threadIdx.x;
-            if (solo_half_step<ND, VARIANT, THERM, NPARTS, 2, MODEL>(pb, pbp, sm, (rel0 + h) >> 1, draws, hint,
-                                                                     g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
-                                                                     rel0 + h >= state_from, tid, run_flags, arrive_goal))
+            if (solo_half_step<ND, VARIANT, THERM, NPARTS, kBoard, MODEL>(pb, pbp, sm, (rel0 + h) >> 1, draws, hint,
+                                                                          g_run0 + rel0 + h, g_run0, i, smem, first_col, first,
+                                                                          rel0 + h >= state_from, tid, run_flags, arrive_goal))
                 return;
             first = false;
         }
@@ -3144,6 +3189,7 @@ struct lcf_sampler {
     bool foreign_stream = false;  // half-steps of the current run were enqueued on a caller's stream
     int half_step_kernel = LCF_HALF_STEP_AUTO;
     int last_kernel = -1;     // what the last run's half-steps were (lcf_sampler_last_run_kernel)
+    bool last_rows = false;   // ... and whether it was a row-board run (between ranks)
     long long last_launches = 0;   // launches of that kernel in the last run (lcf_sampler_last_run_launches)
     unsigned long long* mailbox = nullptr;   // this rank's peer mailbox (uncached device memory), see DevSampler
     size_t mailbox_cap = 0;
@@ -3163,6 +3209,10 @@ struct lcf_sampler {
     bool run_image_valid = false;
     bool run_flip = false;                   // ds.X / LP / nacc name the SECOND set of state buffers
     unsigned int run_arrivals = 0;           // workgroups of resident launches enqueued so far (the board's arrivals word)
+    DevSampler* d_rows_image = nullptr;      // the sampler as k_solo_run<..., RANKS> reads it (rows_image)
+    DevSampler rows_image_host{};
+    bool rows_image_valid = false;
+    unsigned int rows_arrivals = 0;          // the same count for the resident launches of row-board runs (cleared per run)
     int run_capacity = -1;                   // workgroups of k_solo_run the device holds at once (-1: not asked yet)
     size_t run_board_bytes() const {
         return board_rows_bytes(kRunRing, ds.n_walkers, ds.n_dim) + (size_t)kBoardTail * sizeof(unsigned int);
@@ -3594,7 +3644,16 @@ lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
         LCF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
     int per_cu = 0;
     LCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
-    s->run_capacity = per_cu * s->e->n_cus;
+    // (the compute units this stream may use: a CU mask on the stream -- or on the process -- leaves fewer than the device has)
+    int cus = s->e->n_cus;
+    uint32_t mask[16] = {0};
+    if (hipExtStreamGetCUMask(s->e->stream, 16, mask) == hipSuccess) {
+        int bits = 0;
+        for (uint32_t m : mask) bits += __builtin_popcount(m);
+        if (bits > 0 && bits < cus) cus = bits;
+    }
+    (void)hipGetLastError();
+    s->run_capacity = per_cu * cus;
     if (const char* env = std::getenv("LCF_RUN_GRID")) s->run_capacity = std::min(s->run_capacity, std::atoi(env));  // (tests)
     return LCF_OK;
 }
@@ -3637,12 +3696,46 @@ lcf_status run_image(lcf_sampler* s, hipStream_t st, const DevSampler** out, int
     return LCF_OK;
 }
 
+// The same for a rank of a row-board run (k_solo_run<..., RANKS>): the rank's own board and its peers', no second set of
+// state buffers (state and chain are collected from the board), no snapshot words.
+lcf_status rows_image(lcf_sampler* s, hipStream_t st, const DevSampler** out) {
+    DevSampler rs = s->ds;
+    rs.store_chain = rs.inline_finalize = rs.n_peers = 0;
+    rs.X_out = nullptr;
+    rs.LP_out = nullptr;
+    rs.nacc_out = nullptr;
+    rs.snap_out = nullptr;
+    rs.snap_flags = nullptr;
+    if (!s->d_rows_image) {
+        LCF_HIP(hipMalloc((void**)&s->d_rows_image, sizeof(DevSampler)));
+        s->owned.push_back(s->d_rows_image);
+        s->rows_image_valid = false;
+    }
+    if (!s->rows_image_valid || std::memcmp(&rs, &s->rows_image_host, sizeof rs) != 0) {
+        hipLaunchKernelGGL(k_put_image<DevSampler>, dim3(1), dim3(64), 0, st, s->d_rows_image, rs);
+        LCF_HIP(hipGetLastError());
+        std::memcpy(&s->rows_image_host, &rs, sizeof rs);
+        s->rows_image_valid = true;
+    }
+    *out = s->d_rows_image;
+    return LCF_OK;
+}
+
 // Half-steps [rel, rel + n_hs) of the run, all inside the current block of draw records.
-lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
+// `ranks`: this rank's slots [lo, hi) only, rows between the ranks' boards (lcf_sampler_run_rows); `need_progress`: see
+// k_solo_run<..., RANKS>.
+lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st, bool ranks = false, int lo = 0, int hi = 0,
+                      long long need_progress = 0) {
     lcf_engine* e = s->e;
     const DevSampler* rs = nullptr;
     int run_flags = 0;
-    if (lcf_status r = run_image(s, st, &rs, &run_flags)) return r;
+    if (ranks) {
+        if (lcf_status r = rows_image(s, st, &rs)) return r;
+    } else {
+        if (lcf_status r = run_image(s, st, &rs, &run_flags)) return r;
+        lo = 0;
+        hi = s->ds.n_half;
+    }
     const DrawRec* draws = s->rows(rel);
     const size_t lds = solo_lds_bytes(e);
     const long long g_run0 = s->g_run0;
@@ -3650,17 +3743,19 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
     // (test of the recovery from a launch whose workgroups are not all resident: the last one is not launched at all)
     const bool test_missing = std::getenv("LCF_RUN_TEST_MISSING") != nullptr;
     const int spec = specialised_model(e->dp);
-#define LCF_RUN5(ND, NP, M)                                                                                           \
+    unsigned int& arrivals = ranks ? s->rows_arrivals : s->run_arrivals;
+#define LCF_RUN6(ND, NP, M, R)                                                                                        \
     do {                                                                                                              \
-        if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M>, kBlock * 2, lds)) return r;                \
+        if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M, R>, kBlock * 2, lds)) return r;             \
         if (s->run_capacity < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");              \
-        const int n_wg = std::min(s->ds.n_half, s->run_capacity);                                                     \
+        const int n_wg = std::min(hi - lo, s->run_capacity);                                                          \
         const dim3 grid((unsigned)(test_missing && n_wg > 1 ? n_wg - 1 : n_wg));                                      \
-        s->run_arrivals += (unsigned int)n_wg;   /* (0 = "no check": skipped when the count wraps onto it) */          \
-        if (s->run_arrivals == 0u) s->run_arrivals = 1u;                                                              \
-        hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
-                           g_run0, n_hs, state_from, n_wg, run_flags, s->run_arrivals);                               \
+        arrivals += (unsigned int)n_wg;   /* (0 = "no check": skipped when the count wraps onto it) */                 \
+        if (arrivals == 0u) arrivals = 1u;                                                                            \
+        hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M, R>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
+                           g_run0, n_hs, state_from, n_wg, run_flags, arrivals, lo, hi - lo, need_progress);          \
     } while (0)
+#define LCF_RUN5(ND, NP, M) LCF_RUN6(ND, NP, M, false)
 #define LCF_RUN4(ND, NP)                                                                                              \
     do {                                                                                                              \
         if (ND == 5 && spec == kShockCooling) LCF_RUN5(5, NP, kShockCooling);                                         \
@@ -3668,6 +3763,21 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
         else LCF_RUN5(ND, NP, 0);                                                                                     \
     } while (0)
 #define LCF_RUN(ND) do { if (e->dp.n_parts <= 2) LCF_RUN4(ND, 2); else LCF_RUN4(ND, 4); } while (0)
+    if (ranks) {
+        // (between ranks: the benchmark shapes' own kernels, the companion fit's dimension, and the generic kernel with the
+        // dimension at run time for everything else -- every instantiation is a minute of compile time)
+        const bool two = e->dp.n_parts <= 2;
+        if (s->ds.n_dim == 5 && spec == kShockCooling && two) LCF_RUN6(5, 2, kShockCooling, true);
+#ifndef LCF_DEV_BUILD
+        else if (s->ds.n_dim == 4 && spec == kShockCooling2 && two) LCF_RUN6(4, 2, kShockCooling2, true);
+        else if (s->ds.n_dim == 8 && two) LCF_RUN6(8, 2, 0, true);
+        else if (s->ds.n_dim == 8) LCF_RUN6(8, 4, 0, true);
+#endif
+        else if (two) LCF_RUN6(0, 2, 0, true);
+        else LCF_RUN6(0, 4, 0, true);
+        LCF_HIP(hipGetLastError());
+        return LCF_OK;
+    }
     switch (s->ds.n_dim) {
 #ifndef LCF_DEV_BUILD
         case 4: LCF_RUN(4); break;
@@ -3682,6 +3792,7 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st) {
 #undef LCF_RUN
 #undef LCF_RUN4
 #undef LCF_RUN5
+#undef LCF_RUN6
     LCF_HIP(hipGetLastError());
     return LCF_OK;
 }
@@ -4053,7 +4164,7 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
         // the half-step the others gave up on: the ensemble must be set again, on every rank, before the next run)
         const double sec = (double)s->ds.wait_ticks / 1e8;
         unsigned int w[kBoardClear] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const bool run = s->last_kernel == LCF_KERNEL_RUN && s->run_board_mem;
+        const bool run = s->last_kernel == LCF_KERNEL_RUN && s->run_board_mem && !s->last_rows;
         if (run)
             hipMemcpy(w, reinterpret_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - kBoardClear * sizeof(unsigned int),
                       sizeof w, hipMemcpyDeviceToHost);
@@ -4106,11 +4217,19 @@ lcf_status lcf_sampler_check(lcf_sampler* s) {
             return fail(LCF_ERR_STATE, msg);
         }
         if (w[0]) {
-            char msg[200];
+            char msg[300];
             if (w[1] == 1)
                 std::snprintf(msg, sizeof msg, "row-board run: version %u of walker %u (column %u) was not posted within "
                               "%.1f s: a rank is missing or behind (set_state is required on all ranks before the next run)",
                               w[2], w[3], w[4], sec);
+            else if (w[1] == 3)
+                std::snprintf(msg, sizeof msg, "row-board run: version %u of walker %u did not arrive within %.2f s and only "
+                              "%u workgroups of this rank's resident launch had started: another resident kernel holds this "
+                              "GPU (set_state is required on all ranks before the next run)", w[2], w[3],
+                              (double)s->ds.resident_ticks / 1e8, w[4]);
+            else if (s->last_kernel == LCF_KERNEL_RUN)
+                std::snprintf(msg, sizeof msg, "row-board run: the launch from half-step %u waited %.1f s for rank %u to "
+                              "reach half-step %u (set_state is required on all ranks before the next run)", w[2], sec, w[3], w[4]);
             else
                 std::snprintf(msg, sizeof msg, "row-board run: half-step %u waited %.1f s for rank %u to finish half-step "
                               "%u (set_state is required on all ranks before the next run)", w[2], sec, w[3], w[2] - 2);
@@ -4361,6 +4480,15 @@ lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_s
 }  // extern "C"
 
 namespace {
+// Row-board runs with RESIDENT workgroups (k_solo_run<..., RANKS>): where a single-GPU run of the rank's share would
+// take resident workgroups (run_eligible), and for the same reasons.  LCF_ROWS_PER_HALF_STEP=1: never.
+bool rows_resident_eligible(const lcf_sampler* s, int width) {
+    const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr || std::getenv("LCF_ROWS_PER_HALF_STEP") != nullptr;
+    const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;
+    return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) &&
+           ((s->e->dp.n_parts <= 2 ? width <= 4 * kRunSlots : width > s->e->n_cus && width <= kRunSlots) || any_size);
+}
+
 lcf_status board_alloc(lcf_sampler* s) {
     if (s->board_mem) return LCF_OK;
     LCF_HIP(hipSetDevice(s->e->device));
@@ -4433,19 +4561,49 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
     hipStream_t st = s->e->stream;
     DevSampler& ds = s->ds;
     const int width = ds.n_half / ds.n_board_ranks, lo = ds.board_rank * width, hi = lo + width;
-    s->last_kernel = LCF_KERNEL_SOLO;
+    const bool resident = rows_resident_eligible(s, width) && n_steps > 0;
+    s->last_rows = true;
+    s->last_kernel = resident ? LCF_KERNEL_RUN : LCF_KERNEL_SOLO;
+    s->last_launches = resident ? 0 : 2 * n_steps;
     LCF_HIP(hipEventRecord(s->ev0, st));
     const long long cells = (long long)ds.n_walkers * (ds.n_dim + 2);
-    hipLaunchKernelGGL(k_board_init, dim3((unsigned)((std::max<long long>(cells, 5) + 255) / 256)), dim3(256), 0, st, ds,
+    hipLaunchKernelGGL(k_board_init, dim3((unsigned)((std::max<long long>(cells, kBoardClear) + 255) / 256)), dim3(256), 0, st, ds,
                        (unsigned int)s->g_run0);
     LCF_HIP(hipGetLastError());
+    s->rows_arrivals = 0;   // (k_board_init has cleared the word)
     const unsigned collect_blocks = (unsigned)((ds.n_half + 3) / 4);
-    for (int64_t k = 0; k < 2 * n_steps; ++k) {
-        if (lcf_status r = launch_solo(s, k, st, true, lo, hi)) return r;
-        if (store_chain && (k & 1)) {  // the rows of this step's two half-steps, from every rank, into the chain
-            hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds,
-                               (long long)(s->g_run0 + k - 1), (long long)(k / 2), s->rows(k - 1), 2, 0, 1);
-            LCF_HIP(hipGetLastError());
+    if (resident) {
+        // The rank's workgroups stay for a block of up to kRunSpan half-steps (k_solo_run<..., RANKS>); behind every launch
+        // the rows of its half-steps -- as every rank posted them -- go from the board into the chain, behind the last one
+        // the rows of the last step into X / LP / counts.  A launch may start once every rank has reached the launch before
+        // the previous one (need_progress).
+        long long starts[2] = {-1, -1};   // first half-steps (relative) of the two launches in front
+        for (long long rel = 0; rel < 2 * n_steps;) {
+            ++s->last_launches;
+            if (lcf_status r = enter_half_step(s, rel, st)) return r;
+            const int64_t b = s->blk_current;
+            const long long end = 2 * (s->block_start(b) + s->block_len(b));
+            const int n = (int)std::min<long long>(kRunSpan, end - rel);
+            const long long need = starts[0] >= 0 ? s->g_run0 + starts[0] : 0;
+            if (lcf_status r = launch_run(s, rel, n, st, true, lo, hi, need)) return r;
+            if (store_chain) {
+                hipLaunchKernelGGL(k_board_collect, dim3((unsigned)n * collect_blocks), dim3(256), 0, st, ds,
+                                   (long long)(s->g_run0 + rel), (long long)(rel / 2), s->rows(rel), n, 0, 1);
+                LCF_HIP(hipGetLastError());
+            }
+            if (lcf_status r = leave_half_step(s, st)) return r;
+            starts[0] = starts[1];
+            starts[1] = rel;
+            rel += n;
+        }
+    } else {
+        for (int64_t k = 0; k < 2 * n_steps; ++k) {
+            if (lcf_status r = launch_solo(s, k, st, true, lo, hi)) return r;
+            if (store_chain && (k & 1)) {  // the rows of this step's two half-steps, from every rank, into the chain
+                hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds,
+                                   (long long)(s->g_run0 + k - 1), (long long)(k / 2), s->rows(k - 1), 2, 0, 1);
+                LCF_HIP(hipGetLastError());
+            }
         }
     }
     if (n_steps > 0) {  // the last step's rows of all walkers into X / LP / counts
@@ -4472,6 +4630,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     const bool one_launch = run_eligible(s) && n_steps > 0 && run_claim(s->e->device, s->e->stream);
     RunClaim claim{s->e->device, s->e->stream, one_launch};
+    s->last_rows = false;
     if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain,
                                       !solo_eligible(s) || run_eligible(s))) return st;
     hipStream_t st = s->e->stream;

@@ -455,6 +455,67 @@ def as_filter(f):
         raise KeyError(f'unrecognised filter {f!r}') from None
 
 
+_LEVELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'table_levels.npz')
+_levels_bank = False
+
+
+def table_levels(a, w, compress=True, interp=True, t_lo=INTERP_TMIN, t_hi=INTERP_TMAX):
+    """The levels above one filter's full table ``(a, w)``, built and proved here: ``{'cool': (a', W', t_min, bound) or
+    None, 'hot': ..., 'interp': (coef, t_min, bound) or None}`` (see :class:`PackedTables`)."""
+    def quads(n):
+        return (n + 3) // 4
+
+    cool = compress_planck_table(a, w, orders=(8, 12, 16, 20, 24, 28, 32), max_tmin=COOL_TMIN,
+                                 min_ratio=1.) if compress else None
+    if cool is not None and quads(len(cool[0])) >= quads(len(a)):
+        cool = None
+    longer = len(a) if cool is None else len(cool[0])
+    hot = compress_planck_table(a, w, orders=(8, 12, 16), max_tmin=HOT_TMIN, min_ratio=1.) if compress else None
+    if hot is not None and (quads(len(hot[0])) >= quads(longer) or (cool is not None and hot[2] <= cool[2])):
+        hot = None
+    return {'cool': cool, 'hot': hot, 'interp': interp_planck_table(a, w, t_lo=t_lo, t_hi=t_hi) if interp else None}
+
+
+def shipped_levels(filt, a, w, z):
+    """The levels of ``filt``'s plain table at redshift ``z`` from the ones shipped for z = 0, or None (no shipped entry,
+    or the table at hand is not the one the entry was made from).  With ``x = 1 + z``: ``a_k(z) = x a_k(0)`` and
+    ``W_k(z) = x^3 W_k(0)``, so ``S(T; z) = x^3 S(T / x; 0)`` -- a Gauss rule of the z = 0 table is one of this table
+    with nodes ``x a'`` and weights ``x^3 W'`` from ``x t_min`` on, and the interpolant of ``ln S(ln T; 0)`` is the one of
+    this table on the grid shifted by ``ln x`` (``PackedTables.iu0``) plus ``3 ln x``: every proof carries over, to the
+    rounding of the scaling."""
+    global _levels_bank
+    if _levels_bank is False:
+        _levels_bank = np.load(_LEVELS) if os.path.exists(_LEVELS) else None
+    bank = _levels_bank
+    key = 'levels/' + (filt.filename or '')
+    if bank is None or not filt.filename or key + '/n' not in bank.files:
+        return None
+    x = 1. + z
+    # the entry's fingerprint: sample count and the two sums of the z = 0 table
+    if int(bank[key + '/n']) != len(a) or not len(a):
+        return None
+    asum, wsum = float(bank[key + '/asum']), float(bank[key + '/wsum'])
+    if abs(a.sum() - x * asum) > 1e-12 * abs(x * asum) or abs(w.sum() - x ** 3 * wsum) > 1e-12 * abs(x ** 3 * wsum):
+        return None
+    out = {}
+    for name, tag in (('cool', 'c'), ('hot', 'h')):
+        if f'{key}/{tag}a' in bank.files:
+            out[name] = (x * bank[f'{key}/{tag}a'], x ** 3 * bank[f'{key}/{tag}w'], x * float(bank[f'{key}/{tag}tmin']),
+                         float(bank[f'{key}/{tag}bound']))
+        else:
+            out[name] = None
+    if key + '/icoef' in bank.files:
+        coef = bank[key + '/icoef'].copy()
+        coef[:, -1] += 3. * np.log1p(z)
+        t0 = float(bank[key + '/itmin'])
+        # (a filter proved from the first interval stays so: exactly the shifted grid's lower end)
+        tmin = float(np.exp(np.log(INTERP_TMIN) + np.log1p(z))) if t0 == INTERP_TMIN else x * t0
+        out['interp'] = (coef, tmin, float(bank[key + '/ibound']))
+    else:
+        out['interp'] = None
+    return out
+
+
 class PackedTables:
     """Concatenated ``(a_k, W_k)`` tables for a list of distinct filters (CSR layout: ``off[i]:off[i+1]``)."""
 
@@ -480,21 +541,30 @@ class PackedTables:
         #   "hot":  a still shorter one (8, 12 or 16 nodes) good down to HOT_TMIN (8 kK) at most -- where most of a
         #           fit's points are.
         # A level is kept only if it saves at least one quad of samples against the next longer table.
-        def quads(n):
-            return (n + 3) // 4
-
+        # Third level: piecewise polynomials of ln S(ln T) per filter (None where it cannot be proved).
+        # All three come from the levels SHIPPED for the filter's table at z = 0 (data/table_levels.npz, proved when it
+        # was packed: tools/pack_table_levels.py) wherever the table is the plain one -- no cut-off, no reddening --,
+        # scaled to this redshift (shipped_levels: S(T; z) = (1 + z)^3 S(T / (1 + z); 0), exactly); else they are
+        # built and proved here (table_levels: ~30 ms per filter).
+        self.levels_from = []
         levels = {'c': ([], [], [0], [], []), 'h': ([], [], [0], [], [])}
+        self.iu0, self.ih, self.im = float(np.log(INTERP_TMIN)), float(np.log(INTERP_TMAX / INTERP_TMIN) / INTERP_M), INTERP_M
+        plain = compress and not reddening and drop_zeros and not np.isfinite(cutoff_freq) and z > -1. and \
+            os.environ.get('LCF_PACK_LEVELS') != '1'
+        if plain:   # (the interpolants' origin moves with the redshift: the z = 0 blocks then serve as they are)
+            self.iu0 = float(np.log(INTERP_TMIN) + np.log1p(z))
+        self.icoef = np.zeros((len(self.filters), INTERP_M, INTERP_DEGREE + 1))
+        self.itmin = np.full(len(self.filters), np.inf)
+        self.ibound = np.full(len(self.filters), np.nan)
         for i in range(len(self.filters)):
             a, w = self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]]
-            cool = compress_planck_table(a, w, orders=(8, 12, 16, 20, 24, 28, 32), max_tmin=COOL_TMIN,
-                                         min_ratio=1.) if compress else None
-            if cool is not None and quads(len(cool[0])) >= quads(len(a)):
-                cool = None
-            longer = len(a) if cool is None else len(cool[0])
-            hot = compress_planck_table(a, w, orders=(8, 12, 16), max_tmin=HOT_TMIN, min_ratio=1.) if compress else None
-            if hot is not None and (quads(len(hot[0])) >= quads(longer) or (cool is not None and hot[2] <= cool[2])):
-                hot = None
-            for key, comp in (('c', cool), ('h', hot)):
+            lv = shipped_levels(self.filters[i], a, w, z) if plain else None
+            self.levels_from.append('shipped' if lv is not None else 'built')
+            if lv is None:
+                lo_hi = (float(np.exp(self.iu0)), float(np.exp(self.iu0 + self.im * self.ih))) if plain else \
+                    (INTERP_TMIN, INTERP_TMAX)
+                lv = table_levels(a, w, compress, interp=compress and not reddening, t_lo=lo_hi[0], t_hi=lo_hi[1])
+            for key, comp in (('c', lv['cool']), ('h', lv['hot'])):
                 aa, ww, oo, tt, bb = levels[key]
                 if comp is None:
                     tt.append(np.inf)
@@ -505,6 +575,8 @@ class PackedTables:
                     tt.append(comp[2])
                     bb.append(comp[3])
                 oo.append(oo[-1] + (0 if comp is None else len(comp[0])))
+            if lv['interp'] is not None:
+                self.icoef[i], self.itmin[i], self.ibound[i] = lv['interp']
         #: per filter: largest relative error of each compressed level against the full sum, proved on the dense
         #: temperature grid from the level's t_min to 1e5 kK (NaN: the level does not exist)
         for key, names in (('c', ('ca', 'cw', 'coff', 'ctmin', 'cbound')), ('h', ('ha', 'hw', 'hoff', 'htmin', 'hbound'))):
@@ -515,16 +587,10 @@ class PackedTables:
             setattr(self, names[3], np.asarray(tt, dtype=np.float64))
             setattr(self, names[4], np.asarray(bb, dtype=np.float64))
 
-        # third level: piecewise polynomials of ln S(ln T) per filter (None where it cannot be proved)
-        self.iu0, self.ih, self.im = float(np.log(INTERP_TMIN)), float(np.log(INTERP_TMAX / INTERP_TMIN) / INTERP_M), INTERP_M
-        self.icoef = np.zeros((len(self.filters), INTERP_M, INTERP_DEGREE + 1))
-        self.itmin = np.full(len(self.filters), np.inf)
-        self.ibound = np.full(len(self.filters), np.nan)
-        if compress and not reddening:
-            for i in range(len(self.filters)):
-                res = interp_planck_table(self.a[self.off[i]:self.off[i + 1]], self.w[self.off[i]:self.off[i + 1]])
-                if res is not None:
-                    self.icoef[i], self.itmin[i], self.ibound[i] = res
+    @property
+    def itmax(self):
+        """Upper end of the interpolants' range [kK]."""
+        return float(np.exp(self.iu0 + self.im * self.ih))
 
     def interpolants(self, below=0):
         """``(coef[n_filters, m, 8], t_min[n_filters], u0, h)`` as the engines take them.  ``below`` > 0: the table

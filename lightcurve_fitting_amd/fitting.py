@@ -83,6 +83,8 @@ def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p
 
     Returns the sampler (``.chain`` (nwalkers, nsteps, ndim), ``.flatchain``, ``.run_mcmc``, ``.reset``).
     """
+    import time
+    marks = [('call', time.perf_counter())]
     if model_kwargs is not None:
         raise Exception(MODEL_KWARGS_WARNING)
     _prepare_photometry(lc, model)
@@ -101,17 +103,28 @@ def lightcurve_mcmc(lc, model, priors=None, p_min=None, p_max=None, p_lo=None, p
     _check_start_box(model.input_names, priors, p_lo, p_up)
 
     # log_posterior of fitting.py:121-128 lives on the device: priors are baked into the engine
+    marks.append(('checks', time.perf_counter()))
     engine = model.engine_for(lc, use_sigma=use_sigma, sigma_type=sigma_type, priors=priors)
+    marks.append(('engine', time.perf_counter()))
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 31 - 1)) * 2 ** 31 + int(np.random.randint(0, 2 ** 31 - 1))
     sampler = EnsembleSampler(nwalkers, ndim, engine, seed=seed)
 
     start = p_lo + (p_up - p_lo) * np.random.rand(nwalkers, ndim)      # uniform in the starting box
+    marks.append(('sampler', time.perf_counter()))
     burned_in = sampler.run_mcmc(start, nsteps_burnin)
+    marks.append(('burn_in', time.perf_counter()))
     if show or save_plot_as:
         warnings.warn('chain plots are not produced by the MI355X engine; plot sampler.chain with the reference tools')
     sampler.reset()                                                    # keep only the post-burn-in chain
     sampler.run_mcmc(burned_in.coords, nsteps, skip_initial_state_check=True)
+    marks.append(('run', time.perf_counter()))
+    #: seconds of this call, phase by phase, up to the chain complete in HBM (it crosses PCIe when it is first read):
+    #: argument checks and photometry; the engine (band tables packed on the host + device engine created; ~0 when the
+    #: model already holds an engine for this photometry); sampler and starting positions; burn-in; the stored run
+    sampler.timings = {name: t - t0 for (name, t), (_, t0) in zip(marks[1:], marks[:-1])}
+    sampler.timings['total'] = marks[-1][1] - marks[0][1]
+    sampler.timings['engine_parts'] = dict(getattr(engine, 'timings', {}))
     if save_sampler_as:
         print('saving sampler.flatchain as ' + save_sampler_as)
         np.save(save_sampler_as, sampler.flatchain)

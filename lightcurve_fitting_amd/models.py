@@ -196,9 +196,12 @@ class Model:
             st = _eng.SIGMA_ABSOLUTE
         else:
             raise Exception('sigma_type must either be "relative" or "absolute"')
+        import time
+        t0 = time.perf_counter()
         filts = [as_filter(f) for f in filts]
         uniq, idx = _index_filters(filts)
         tabs = PackedTables(uniq, z=self.z, compress=not self.reddened, reddening=self.reddened)
+        t1 = time.perf_counter()
         pri = None if priors is None else [p.descriptor() for p in priors]
         eng = _eng.Engine(self.model_id, self.n_model_params, self._consts(), t, y, dy, idx, tabs.off, tabs.a, tabs.w,
                           use_sigma=use_sigma, sigma_type=st, priors=pri,
@@ -208,6 +211,8 @@ class Model:
                           itab=None if self.reddened else (tabs.icoef, tabs.itmin, tabs.iu0, tabs.ih),
                           tab_ext=tabs.ext)
         eng.tables, eng.filt_idx = tabs, idx   # what was packed (measurement tools count the samples a fit executes)
+        #: seconds: band tables packed on the host (their levels shipped or built: tabs.levels_from) / engine created
+        eng.timings = {'tables_s': t1 - t0, 'create_s': time.perf_counter() - t1, 'levels': sorted(set(tabs.levels_from))}
         return eng
 
     def engine_for(self, lc, use_sigma=False, sigma_type='relative', priors=None):

@@ -281,9 +281,11 @@ def test_peer_mailboxes_emulated_ranks(ranks):
         assert np.array_equal(s.naccepted(), want_acc)
 
 
+@pytest.mark.parametrize('form', ['resident', 'per half-step'])
 @pytest.mark.parametrize('ranks,nwalkers,split', [(2, 48, 'random'), (3, 54, 'random'), (2, 44, 'identity'), (3, 42, 'random')])
-def test_row_boards_emulated_ranks(ranks, nwalkers, split):
-    """The sharded run in which nothing is replicated: every emulated rank moves ITS share of the walkers with k_solo and
+def test_row_boards_emulated_ranks(ranks, nwalkers, split, form):
+    """The sharded run in which nothing is replicated: every emulated rank moves ITS share of the walkers -- with resident
+    workgroups (k_solo_run<..., RANKS>: a launch per block of half-steps) or with a k_solo launch per half-step -- and
     posts their rows (position, log-posterior, acceptance count) on all boards; state, counts and chain are complete on
     every rank at the end and equal the single-GPU run bit for bit -- also across two runs that continue each other,
     with a fixed colouring, and with 21 slots per half-step shared by 3 ranks (42 walkers)."""
@@ -302,11 +304,13 @@ def test_row_boards_emulated_ranks(ranks, nwalkers, split):
         s.set_state(x0)                       # (size every buffer first: see the mailbox test above)
         s.run(100, nsteps, split, True)
         s.set_state(x0)
+        s.set_half_step_kernel('auto' if form == 'resident' else 'solo')
     for first, n in ((0, 4), (4, nsteps - 4)):
         for s in samplers:
             s.run_rows(first, n, split, True, asynchronous=True)
         for s in samplers:
             s.wait()
+            assert s.last_run_kernel() == ('run' if form == 'resident' else 'solo')
     for s in samplers:
         chain, lp = s.get_chain()
         assert np.array_equal(chain, want_chain[4:]) and np.array_equal(lp, want_lp[4:])
@@ -315,20 +319,39 @@ def test_row_boards_emulated_ranks(ranks, nwalkers, split):
         assert np.array_equal(x, want_x) and np.array_equal(lp_end, want_lp_end)
 
 
-@pytest.mark.parametrize('ranks', [2, 3])
-def test_row_boards_between_processes(ranks):
-    """Real processes, HIP IPC: tools/peer_ranks_check.py with the row boards."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'peer_ranks_check.py'), str(ranks), '48', '10', 'rows'],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['every_rank_equals_the_single_gpu_chain'] and line['connected_on_every_rank'] and line['driver'] == 'rows'
+@pytest.mark.parametrize('ranks,nwalkers,block', [(2, 40, None), (3, 36, '5')])
+def test_resident_row_boards_across_launches_and_draw_blocks(ranks, nwalkers, block, monkeypatch):
+    """A row-board run of 150 steps with resident workgroups: five launches per rank (32 steps each; every launch from the
+    third on waits for the other ranks' progress words), the seam between the first block of draw records and the next --
+    and, with blocks of 5 steps, thirty launches of ten half-steps.  Chain, state and counts of every rank equal the
+    single-GPU run's."""
+    if block:
+        monkeypatch.setenv('LCF_DRAW_BLOCK', block)
+    pb, eng = _multiband()
+    nsteps = 150
+    x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(14).standard_normal((nwalkers, 5)))
+    _, want_chain, want_lp, want_acc, ref = _run(eng, nwalkers, 99, x0, nsteps, 'solo')
+    priors = [M.UniformPrior(0., 10.)] * 3 + [M.UniformPrior(0., 2.2)] + [M.UniformPrior(-1., 0.5)]
+    lc = lc_dict(pb['t'], [b.name for b in pb['bands']], pb['y'], pb['dy'])
+    engines = [M.ShockCooling(redshift=0.004).engine_for(lc, priors=priors) for _ in range(ranks)]
+    samplers = [NativeSampler(e, nwalkers, 99) for e in engines]
+    ptrs = [s.board_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.board_connect(ranks, r, local_ptrs=ptrs)
+        s.set_state(x0)
+        s.run(1000, nsteps, 'random', True)   # (size every buffer first)
+        s.set_state(x0)
+    for s in samplers:
+        s.run_rows(0, nsteps, 'random', True, asynchronous=True)
+    for s in samplers:
+        s.wait()
+        assert s.last_run_kernel() == 'run' and s.last_run_launches() == (30 if block else 5)
+    for s in samplers:
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
+        assert np.array_equal(s.naccepted(), want_acc)
+        for a, b in zip(s.get_state(), ref.get_state()):
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('ranks', [2, 3])
@@ -345,6 +368,26 @@ def test_peer_mailboxes_between_processes(ranks):
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['every_rank_equals_the_single_gpu_chain'] and line['peer_mailboxes_connected_on_every_rank']
+
+
+@pytest.mark.parametrize('ranks,steps', [(2, 10), (3, 140)])
+def test_resident_row_boards_between_processes(ranks, steps):
+    """Real processes, boards mapped through HIP IPC, every rank's workgroups resident for up to 32 steps
+    (k_solo_run<..., RANKS>; 140 steps in two runs of 70: three launches each, the third behind the other ranks' progress
+    words): every rank ends with the single-GPU chain, state and counts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LCF_COLLECTIVE')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'peer_ranks_check.py'), str(ranks), '48', str(steps), 'rows'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['every_rank_equals_the_single_gpu_chain'] and line['connected_on_every_rank']
+    assert line['half_step_kernel_of_the_last_run'] == ['run'] * ranks
+    assert line['its_launches'] == [1 if steps == 10 else 3] * ranks
 
 
 def test_collective_none_probes_and_picks_a_driver_between_processes():
@@ -438,7 +481,8 @@ def test_row_boards_companion_shape():
         assert np.array_equal(s.naccepted(), ref.naccepted())
 
 
-def test_row_boards_missing_rank_ends_with_an_error(monkeypatch):
+@pytest.mark.parametrize('form', ['resident', 'per half-step'])
+def test_row_boards_missing_rank_ends_with_an_error(monkeypatch, form):
     """A rank that never runs: the waits of the other one are bounded (LCF_PEER_WAIT_S, here 0.5 s; 5 s by default), the
     run ends with LCF_ERR_STATE, says which row was missing and that the ensemble must be set again -- it does not hang
     the device."""
@@ -456,10 +500,12 @@ def test_row_boards_missing_rank_ends_with_an_error(monkeypatch):
     for r, s in enumerate(samplers):
         s.board_connect(2, r, local_ptrs=ptrs)
         s.set_state(x0)
+        s.set_half_step_kernel('auto' if form == 'resident' else 'solo')
     t0 = time.perf_counter()
     with pytest.raises(LcfError) as err:
         samplers[0].run_rows(0, 6, 'random', True)     # rank 1 never starts
     assert time.perf_counter() - t0 < 5.
+    assert samplers[0].last_run_kernel() == ('run' if form == 'resident' else 'solo')
     assert err.value.status == 7 and 'was not posted within 0.5 s' in str(err.value) and 'set_state is required' in str(err.value)
     # the sampler is usable again after a new set_state
     samplers[0].set_state(x0)

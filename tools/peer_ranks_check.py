@@ -73,7 +73,8 @@ def main():
                 np.array_equal(s._state[0], ref._state[0]))
     flags = [None] * n_ranks
     connected = s._boards if driver == 'rows' else s._peers if driver == 'peers' else True
-    dist.all_gather_object(flags, (same, bool(connected), float(s.last_run_ms)))
+    dist.all_gather_object(flags, (same, bool(connected), float(s.last_run_ms), s._native.last_run_kernel(),
+                                   s._native.last_run_launches()))
     if rank == 0:
         print(json.dumps({'ranks': n_ranks, 'walkers': n_walkers, 'steps': n_steps,
                           'every_rank_equals_the_single_gpu_chain': all(f[0] for f in flags),
@@ -81,6 +82,7 @@ def main():
                           'probe': probe, 'connected_on_every_rank': all(f[1] for f in flags),
                           'peer_mailboxes_connected_on_every_rank': driver == 'peers' and all(f[1] for f in flags),
                           'device_ms_last_run': [f[2] for f in flags],
+                          'half_step_kernel_of_the_last_run': [f[3] for f in flags], 'its_launches': [f[4] for f in flags],
                           'acceptance': float(s.acceptance_fraction.mean())}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
