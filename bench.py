@@ -173,8 +173,9 @@ def init_distributed(args):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if os.environ.get('LCF_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
-        # (ranks that share a device: the resident launches of two processes could keep each other's workgroups out)
-        os.environ['LCF_NO_RUN_KERNEL'] = '1'
+        # (ranks that share a device: their resident launches must fit the device side by side -- the dry runs use
+        # ensembles of 128 proposals per rank and half-step; a launch that finds its workgroups not all started gives up
+        # after 50 ms and the steps are repeated launch by launch)
         torch.cuda.set_device(0)
         dist.init_process_group('gloo', rank=rank, world_size=world)
     else:
@@ -348,9 +349,9 @@ def kernel_source_sha():
 
 
 def committed_pmc(tag):
-    """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r03_pmc_<tag>.json, written
+    """Counters of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r04_pmc_<tag>.json, written
     by tools/collect_profiles.sh; counters cannot be read from inside this process) -- or the reason they are not used."""
-    path = os.path.join(ROOT, 'profiles', f'r03_pmc_{tag}.json')
+    path = os.path.join(ROOT, 'profiles', f'r04_pmc_{tag}.json')
     try:
         doc = json.load(open(path))
     except Exception as exc:  # noqa: BLE001
@@ -385,7 +386,10 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
     out = {'bound': 'valu-issue', 'achieved': achieved, 'peak': peak, 'unit': 'Tinstr/s', 'frac': achieved / peak,
            'kernel': kernel, 'kernel_ms': kern_ms, 'evaluations_per_launch': evals_per_launch,
            'basis': basis + (' (counted by the build in the ISA of the library that runs: csrc/liblcf_hip.isa.json, '
-                             'tools/isa_count.py): the likelihood loops only, a lower bound of the instructions issued'
+                             'tools/isa_count.py -- in k_solo<5,1,true,2,false,ShockCooling> and its generic twin, the '
+                             'launch-per-half-step kernels: the resident launch runs the same inlined half-step body, '
+                             'plus spill code of its own that is not counted): the likelihood loops only, a lower bound '
+                             'of the instructions issued'
                              if isa_note is None else f' -- {isa_note}'),
            'algorithmic_speedup': evals_per_launch * alg_instr_per_eval / sec / 1e12 / peak,
            'algorithmic_speedup_note': "SURVEY 8d's instruction count of the reference's algorithm per second / the "
@@ -418,7 +422,7 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
             simd_cycles = 1024 * c['GRBM_GUI_ACTIVE'] / 8. * (c['SQ_WAVES'] / waves)
             ex['valu_busy'] = 4. * c['SQ_ACTIVE_INST_VALU'] / simd_cycles
         out['executed_pmc'] = ex
-    out['pmc_provenance'] = {'file': f'profiles/r03_pmc_{pmc_tag}.json', 'collected_at_commit': doc.get('collected_at_commit'),
+    out['pmc_provenance'] = {'file': f'profiles/r04_pmc_{pmc_tag}.json', 'collected_at_commit': doc.get('collected_at_commit'),
                              'kernel_source_sha256': doc.get('kernel_source_sha256')[:16], 'kernel': doc.get('kernel')}
     return out
 
@@ -953,7 +957,7 @@ def run_sed(args):
         if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
             roof['traffic'] = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.
             roof['traffic_unit'] = 'bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE)'
-        roof['pmc_provenance'] = {'file': 'profiles/r03_pmc_k_sed.json', 'collected_at_commit': doc.get('collected_at_commit'),
+        roof['pmc_provenance'] = {'file': 'profiles/r04_pmc_k_sed.json', 'collected_at_commit': doc.get('collected_at_commit'),
                                   'kernel': doc.get('kernel')}
     line = {'metric': 'SED candidate evaluations/sec', 'value': n_ep * n_c / (ms * 1e-3),
             'unit': 'candidates/s', 'n_gpus': 1, 'steps': reps, 'warmup': 1, 'ms_per_step': ms,

@@ -268,11 +268,26 @@ __device__ __forceinline__ double point_model(const DevProblem& pb, const double
 #ifdef LCF_STAMPS
 __device__ unsigned long long g_wall[2 * 1024 * 2];   // [launch parity][workgroup][entry, exit] of the 100 MHz wall clock
 __device__ unsigned long long g_stamps[64 * 16];
+// ... and, for wave 0, the ticks since its previous stamp summed over all half-steps of all launches (g_acc) with the
+// number of times the stamp was passed (g_cnt): the mean life of a workgroup, phase by phase (resident launches: the
+// last half-step alone says little -- it writes the state and the snapshot).
+__device__ unsigned long long g_acc[64 * 16], g_cnt[64 * 16], g_last[64];
+__shared__ unsigned long long s_stamp_last;   // (wave 0's previous stamp; garbage at kernel entry: implausible deltas are dropped)
 #define LCF_STAMP(W, k)                                                                                        \
     do {                                                                                                       \
         unsigned long long t_;                                                                                 \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
-        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) g_stamps[blockIdx.x * 16 + (k)] = t_;                  \
+        if (blockIdx.x < 64 && threadIdx.x == 64 * (W)) {                                                      \
+            g_stamps[blockIdx.x * 16 + (k)] = t_;                                                              \
+            if ((W) == 0) {                                                                                    \
+                const unsigned long long d_ = t_ - s_stamp_last;                                               \
+                if (d_ < (1ull << 24)) {   /* (fire-and-forget adds: nothing here waits for memory) */         \
+                    atomicAdd(&g_acc[blockIdx.x * 16 + (k)], d_);                                              \
+                    atomicAdd(&g_cnt[blockIdx.x * 16 + (k)], 1ull);                                            \
+                }                                                                                              \
+                s_stamp_last = t_;                                                                             \
+            }                                                                                                  \
+        }                                                                                                      \
     } while (0)
 #elif defined(LCF_PROGRESS)
 // Diagnostic build (-DLCF_PROGRESS; never shipped): how often each workgroup has passed each stamp -- where the
@@ -2101,6 +2116,10 @@ void k_solo_run(const DevProblem* __restrict__ pbp, const DevSampler* __restrict
             }
     }
     const int slot_end = slot_lo + n_slots;
+    // (Measured and dropped: the draw record of the NEXT half-step requested one half-step ahead -- by a wave beside the head
+    // into LDS, or as a scalar load carried in registers across the half-step -- instead of the touch that only brings
+    // it into this XCD's L2: 5.80 / 5.94 against 5.51 us per half-step.  The record's two round trips are hidden
+    // already; what the extra live registers cost is not.)
 #pragma unroll 1
     for (int h = 0; h < n_hs; ++h) {
         const DrawRec* draws = draws0 + (size_t)h * sm.n_half;
@@ -3896,8 +3915,10 @@ lcf_status reserve_chain(lcf_sampler* s, int64_t n_steps) {
 // Start a run of n_steps steps: settle what the previous run left pending, size the chain and the draw blocks, and
 // enqueue the generation of the first block.  Nothing here waits for the device unless a buffer has to grow.
 // `need_slots`: the draw records carry each walker's slot in the previous half-step (every path except k_solo).
+// `gen`: the stream the first block of draw records is generated on (default: the engine's own -- where a single
+// sampler's half-steps follow; a population's half-steps all run on ONE stream, and so do its samplers' records).
 lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode, const int32_t* perm,
-                         int32_t store_chain, bool need_slots) {
+                         int32_t store_chain, bool need_slots, hipStream_t gen = nullptr) {
     if (!s || n_steps < 0 || first_step < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
     if (split_mode < LCF_SPLIT_IDENTITY || split_mode > LCF_SPLIT_HOST)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad split_mode");
@@ -3972,13 +3993,14 @@ lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, in
     }
     s->blk_steps = s->blk_cap;
     s->blk_first = std::min<int64_t>(s->blk_cap, LCF_FIRST_BLOCK);
-    if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown) {
+    if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown &&
+        (gen == nullptr || gen == e->stream)) {   // (a block speculated on the engine's stream is not ordered with another)
         s->spec_first = -1;  // the previous run left this run's first block behind (speculate_continuation)
         s->blk_generated = 0;
         return LCF_OK;
     }
     s->spec_first = -1;
-    return generate_block(s, 0, e->stream);
+    return generate_block(s, 0, gen ? gen : e->stream);
 }
 
 }  // namespace
@@ -4743,9 +4765,15 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             return fail(LCF_ERR_UNSUPPORTED, "transients of one batched run must agree on device, walker count, "
                                              "band-sum variant, thermal sharing and table placement");
     }
+    // Everything of this run -- every transient's draw records, the half-steps, the snapshots -- goes on ONE stream (the
+    // first transient's): stream order is all the synchronisation there is.  What the transients' own streams still hold
+    // (set_state, an earlier run of their own) is waited for once, here.
+    LCF_HIP(hipSetDevice(s0->e->device));
+    LCF_HIP(hipDeviceSynchronize());
+    hipStream_t pop_stream = s0->e->stream;
     long long g = 0;
     for (int t = 0; t < n; ++t) {
-        if (lcf_status st = lcf_sampler_begin(ss[t], first_step, n_steps, split_mode, nullptr, store_chain)) return st;
+        if (lcf_status st = sampler_begin(ss[t], first_step, n_steps, split_mode, nullptr, store_chain, true, pop_stream)) return st;
         g = std::max(g, ss[t]->g_next);
     }
     std::vector<MultiItem> items(n);
@@ -4879,6 +4907,14 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipEventRecord(ev1, st);
+    // every transient's snapshot (error word, state, counts) behind the run, on the same stream: ONE wait below serves
+    // the 32 state / count / check calls that follow (each of them used to synchronise and launch on its own)
+    for (int t = 0; t < n && err == hipSuccess; ++t) {
+        const long long words = (long long)(ss[t]->snap_bytes() / 8);
+        hipLaunchKernelGGL(k_snapshot, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ss[t]->ds,
+                           reinterpret_cast<unsigned long long*>(ss[t]->snap));
+        err = hipGetLastError();
+    }
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     hipFree(ditems);
     LCF_HIP(err);
@@ -4887,7 +4923,11 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int t = 0; t < n; ++t) {
         ss[t]->g_next = g + 2 * n_steps;
         ss[t]->pending = false;
+        ss[t]->foreign_stream = false;      // (the stream has been waited for)
+        ss[t]->snap_enqueued = false;
+        ss[t]->snap_valid = true;
         ss[t]->last_ms = ms;
+        ss[t]->last_rows = false;
         ss[t]->last_kernel = one_launch ? LCF_KERNEL_POPULATION : LCF_KERNEL_POPULATION_PHASES;
     }
     for (int t = 0; t < n; ++t)
@@ -4931,6 +4971,18 @@ extern "C" int lcf_debug_read_progress(unsigned int* out) {
 }
 #endif
 #ifdef LCF_STAMPS
+// (sums and counts, 64 x 16 each; `reset` != 0: cleared afterwards, with the "previous stamp" of every workgroup)
+extern "C" int lcf_debug_read_stamp_sums(unsigned long long* acc, unsigned long long* cnt, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_acc), sizeof(unsigned long long) * 64 * 16);
+    rc |= (int)hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_cnt), sizeof(unsigned long long) * 64 * 16);
+    if (reset) {
+        static unsigned long long zeros[64 * 16];
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_acc), zeros, sizeof zeros);
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cnt), zeros, sizeof zeros);
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_last), zeros, sizeof(unsigned long long) * 64);
+    }
+    return rc;
+}
 extern "C" int lcf_debug_read_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64 * 16);
 }

@@ -2,9 +2,9 @@
 # Collect the rocprofv3 evidence behind bench.py's roofline numbers (run on the GPU box through gpurun, LAST in a round:
 # the PMC summaries carry the hash of the kernel sources they were collected from, and bench.py uses them only while
 # that hash matches the tree).
-#   bash tools/collect_profiles.sh r03 [commit]
+#   bash tools/collect_profiles.sh r04 [commit]
 # kernel-trace/stats and every --pmc pass are separate runs, as the profiling guide prescribes.
-TAG=${1:-r03}
+TAG=${1:-r04}
 COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
