@@ -210,6 +210,9 @@ lcf_status lcf_population_run(lcf_sampler** samplers, int32_t n, int64_t first_s
 /* Chain of the last run: chain[n_steps][n_walkers][n_dim], log_prob[n_steps][n_walkers] (either may be NULL). */
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob);
 lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted /* [n_walkers] */);
+/* lcf_sampler_get_state and lcf_sampler_get_naccepted in ONE call (any pointer may be NULL): what a driver reads after
+ * every run -- emcee's State and the acceptance counts (fitting.py:133, 145) -- for one trip through the binding. */
+lcf_status lcf_sampler_get_snapshot(lcf_sampler* s, double* coords, double* log_prob, int64_t* n_accepted);
 /* Device time of the last lcf_sampler_run in milliseconds (HIP events on the sampler's stream). */
 double lcf_sampler_last_run_ms(const lcf_sampler* s);
 /* 1 if half-steps of this sampler run as one launch (everything a workgroup needs fits in LDS), 0 if as

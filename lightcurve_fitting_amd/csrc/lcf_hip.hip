@@ -1657,8 +1657,19 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
     if (BOARD) {
         const bool own = lane >= 16;
         const int col = own ? lane - 16 : lane;
-        if (own ? col <= nd + 1 : col < nd)
+        if (own ? col <= nd + 1 : col < nd) {
+#ifdef LCF_EXPERIMENT_NOPOLL   // (timing experiment, wrong chain: the state in memory instead of the rows the half-step needs:
+            // one load past the caches, as a poll that finds its row at once, and no waiting for anybody)
+            {
+                const int w_ = own ? dr.wid : dr.pid;
+                const double* src_ = col < nd ? sm.X + (size_t)w_ * nd + col : col == nd ? sm.LP + w_ : sm.LP + w_;
+                h.got = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(src_),
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+            }
+#else
             h.got = board_take<BOARD == 2>(sm, board_tag(G, own ? dr.wage : dr.page, g_run0), own ? dr.wid : dr.pid, col, arrive_goal);
+#endif
+        }
     }
     h.lp_i = BOARD ? lane_value(h.got, 16 + nd) : sm.LP[dr.wid];
 #pragma unroll
@@ -1666,6 +1677,8 @@ __device__ __forceinline__ void head_fetch(const DevProblem& pb, const DevSample
         h.x[d] = d < nd ? (BOARD ? lane_value(h.got, 16 + d) : xs[d]) : 0.;
         h.cj[d] = d < nd ? (BOARD ? lane_value(h.got, d) : cs_[d]) : 0.;
     }
+    // (measured: requesting the prior in FRONT of the poll instead changes nothing -- 5.45 against 5.43 us; its way from L2
+    // is hidden behind the logarithms either way)
     h.prior = PriorDev{0, 0, 0., 0., 0., 1.};
     if (lane < pb.n_dim && pb.has_priors) h.prior = pb.priors[lane];
 }
@@ -1817,7 +1830,18 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
         // Touch the draw record this block index needs in the NEXT launch: block -> XCD placement repeats from launch
         // to launch, so the record is then in this XCD's L2 instead of HBM when the next serial head starts with it
         // (a hint only: nothing depends on the value or on the placement).
-        if (tid == 64 && draws_next != nullptr) {
+        if (BOARD >= 2) {
+            // Resident launches: the record is read by a SCALAR load at the top of the next half-step, so it is the scalar
+            // cache of this CU that should hold it by then -- two scalar loads (the record may straddle a line), waited for
+            // here, by a wave that has nothing else to do in the shadow of the head (5.51 -> 5.42 us per half-step against
+            // the vector touch below, which only brings the record into the XCD's L2).
+            if (tid >= 64 && tid < 128 && draws_next != nullptr) {
+                const int* nxt = reinterpret_cast<const int*>(draws_next + i);
+                int a_, b_;
+                asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x2c\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&s"(a_), "=&s"(b_) : "s"(nxt) : "memory");
+            }
+        } else if (tid == 64 && draws_next != nullptr) {
             const volatile int* nxt = reinterpret_cast<const volatile int*>(draws_next + i);
             (void)nxt[0];
             (void)nxt[sizeof(DrawRec) / sizeof(int) - 1];
@@ -1868,7 +1892,11 @@ __device__ __forceinline__ bool solo_half_step(const DevProblem& pb, const DevPr
             double acc = 0.;
             if (c0 + (ltid & ~63) < c1) {   // (a virtual wave without columns adds nothing)
                 const bool live = c0 + ltid < c1;
+#ifdef LCF_EXPERIMENT_NOCOLUMNS   // (timing experiment, wrong chain: no likelihood arithmetic)
+                if (false)
+#else
                 if (!lean_column<MODEL>(pb, sc, first_col, ExpTab{exptab}, itab_at, acc))
+#endif
                     acc = cold_column_with_state<VARIANT, MODEL>(pbp, sc, sq, first_col.t, min(c0 + ltid, c1 - 1), live);
                 term = live ? acc : 0.;     // (lanes beyond the part repeated its last column)
             }
@@ -3233,6 +3261,7 @@ struct lcf_sampler {
     bool rows_image_valid = false;
     unsigned int rows_arrivals = 0;          // the same count for the resident launches of row-board runs (cleared per run)
     int run_capacity = -1;                   // workgroups of k_solo_run the device holds at once (-1: not asked yet)
+    int run_capacity_wide = -1;              // ... of its 1024-thread form (NPARTS = 8)
     size_t run_board_bytes() const {
         return board_rows_bytes(kRunRing, ds.n_walkers, ds.n_dim) + (size_t)kBoardTail * sizeof(unsigned int);
     }
@@ -3609,11 +3638,24 @@ lcf_status launch_solo(lcf_sampler* s, long long rel, hipStream_t st, bool board
 // of the 1024-thread workgroups that k_solo uses for launches of at most one workgroup per CU): they take it above one
 // proposal per CU, up to 512.
 constexpr int kRunSlots = 512;
+// Launches of at most one workgroup per CU of light curves with more than two parts (a rank's share of a strongly scaled
+// ensemble: configs[2] on 8 GPUs, 256 proposals): 1024-thread workgroups, all four parts of a proposal side by side, as
+// k_solo uses for such launches -- resident, for the eight-parameter models (the instantiation that exists).
+// (LCF_WIDE_RUNS=0: launches that k_solo's 1024-thread workgroups would take keep a launch per half-step)
+bool wide_runs() {
+    const char* env = std::getenv("LCF_WIDE_RUNS");
+    return !(env && env[0] == '0');
+}
+bool run_wide(const lcf_sampler* s, int proposals) {
+    static const bool no_wide = std::getenv("LCF_NO_WIDE_SOLO") != nullptr;
+    return !no_wide && s->e->dp.n_parts > 2 && proposals <= s->e->n_cus && s->ds.n_dim == 8;
+}
 bool run_eligible(const lcf_sampler* s) {
     static const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
     static const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;   // (tests: several slots per workgroup)
     return !disabled && !s->run_off && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) && s->ds.n_peers == 0 &&
-           ((s->e->dp.n_parts <= 2 ? s->ds.n_half <= 4 * kRunSlots : s->ds.n_half > s->e->n_cus && s->ds.n_half <= kRunSlots) ||
+           ((s->e->dp.n_parts <= 2 ? s->ds.n_half <= 4 * kRunSlots
+                                   : (s->ds.n_half > s->e->n_cus || (wide_runs() && run_wide(s, s->ds.n_half))) && s->ds.n_half <= kRunSlots) ||
             any_size);
 }
 
@@ -3658,9 +3700,10 @@ struct RunClaim {   // releases on every path out of the enqueue
 
 template <class K>
 lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
-    if (s->run_capacity >= 0) return LCF_OK;
-    if (lds > 64 * 1024)
-        LCF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
+    int& cap = threads > kBlock * 2 ? s->run_capacity_wide : s->run_capacity;
+    if (cap >= 0) return LCF_OK;
+    if (lds > 64 * 1024)   // (what the launch asks for, not the CU's whole LDS: the kernel may hold static words of its own)
+        LCF_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     LCF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
     // (the compute units this stream may use: a CU mask on the stream -- or on the process -- leaves fewer than the device has)
@@ -3672,8 +3715,8 @@ lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
         if (bits > 0 && bits < cus) cus = bits;
     }
     (void)hipGetLastError();
-    s->run_capacity = per_cu * cus;
-    if (const char* env = std::getenv("LCF_RUN_GRID")) s->run_capacity = std::min(s->run_capacity, std::atoi(env));  // (tests)
+    cap = per_cu * cus;
+    if (const char* env = std::getenv("LCF_RUN_GRID")) cap = std::min(cap, std::atoi(env));  // (tests)
     return LCF_OK;
 }
 
@@ -3765,13 +3808,15 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st, b
     unsigned int& arrivals = ranks ? s->rows_arrivals : s->run_arrivals;
 #define LCF_RUN6(ND, NP, M, R)                                                                                        \
     do {                                                                                                              \
-        if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M, R>, kBlock * 2, lds)) return r;             \
-        if (s->run_capacity < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");              \
-        const int n_wg = std::min(hi - lo, s->run_capacity);                                                          \
+        constexpr int kThr = kBlock * (NP == 8 ? 4 : 2);                                                              \
+        if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M, R>, kThr, lds)) return r;                   \
+        const int cap = NP == 8 ? s->run_capacity_wide : s->run_capacity;                                             \
+        if (cap < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");                          \
+        const int n_wg = std::min(hi - lo, cap);                                                                      \
         const dim3 grid((unsigned)(test_missing && n_wg > 1 ? n_wg - 1 : n_wg));                                      \
         arrivals += (unsigned int)n_wg;   /* (0 = "no check": skipped when the count wraps onto it) */                 \
         if (arrivals == 0u) arrivals = 1u;                                                                            \
-        hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M, R>), grid, dim3(kBlock * 2), lds, st, e->d_dp, rs, rel, draws, \
+        hipLaunchKernelGGL((k_solo_run<ND, 1, true, NP, M, R>), grid, dim3(kThr), lds, st, e->d_dp, rs, rel, draws,    \
                            g_run0, n_hs, state_from, n_wg, run_flags, arrivals, lo, hi - lo, need_progress);          \
     } while (0)
 #define LCF_RUN5(ND, NP, M) LCF_RUN6(ND, NP, M, false)
@@ -3786,14 +3831,21 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st, b
         // (between ranks: the benchmark shapes' own kernels, the companion fit's dimension, and the generic kernel with the
         // dimension at run time for everything else -- every instantiation is a minute of compile time)
         const bool two = e->dp.n_parts <= 2;
+        const bool wide = run_wide(s, hi - lo);   // (1024-thread workgroups, the four parts of a proposal side by side)
         if (s->ds.n_dim == 5 && spec == kShockCooling && two) LCF_RUN6(5, 2, kShockCooling, true);
 #ifndef LCF_DEV_BUILD
         else if (s->ds.n_dim == 4 && spec == kShockCooling2 && two) LCF_RUN6(4, 2, kShockCooling2, true);
         else if (s->ds.n_dim == 8 && two) LCF_RUN6(8, 2, 0, true);
+        else if (s->ds.n_dim == 8 && wide) LCF_RUN6(8, 8, 0, true);
         else if (s->ds.n_dim == 8) LCF_RUN6(8, 4, 0, true);
 #endif
         else if (two) LCF_RUN6(0, 2, 0, true);
         else LCF_RUN6(0, 4, 0, true);
+        LCF_HIP(hipGetLastError());
+        return LCF_OK;
+    }
+    if (s->ds.n_dim == 8 && run_wide(s, hi - lo)) {
+        LCF_RUN6(8, 8, 0, false);
         LCF_HIP(hipGetLastError());
         return LCF_OK;
     }
@@ -4508,7 +4560,8 @@ bool rows_resident_eligible(const lcf_sampler* s, int width) {
     const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr || std::getenv("LCF_ROWS_PER_HALF_STEP") != nullptr;
     const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;
     return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) &&
-           ((s->e->dp.n_parts <= 2 ? width <= 4 * kRunSlots : width > s->e->n_cus && width <= kRunSlots) || any_size);
+           ((s->e->dp.n_parts <= 2 ? width <= 4 * kRunSlots
+                                   : (width > s->e->n_cus || (wide_runs() && run_wide(s, width))) && width <= kRunSlots) || any_size);
 }
 
 lcf_status board_alloc(lcf_sampler* s) {
@@ -4951,6 +5004,15 @@ lcf_status lcf_sampler_get_naccepted(lcf_sampler* s, int64_t* n_accepted) {
     if (!s || !n_accepted) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     if (lcf_status st = settle(s)) return st;
     std::memcpy(n_accepted, s->snap + s->snap_acc(), s->snap_bytes() - s->snap_acc());
+    return LCF_OK;
+}
+
+lcf_status lcf_sampler_get_snapshot(lcf_sampler* s, double* coords, double* log_prob, int64_t* n_accepted) {
+    if (!s) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
+    if (lcf_status st = settle(s)) return st;
+    if (coords) std::memcpy(coords, s->snap + s->snap_x(), s->snap_lp() - s->snap_x());
+    if (log_prob) std::memcpy(log_prob, s->snap + s->snap_lp(), s->snap_acc() - s->snap_lp());
+    if (n_accepted) std::memcpy(n_accepted, s->snap + s->snap_acc(), s->snap_bytes() - s->snap_acc());
     return LCF_OK;
 }
 

@@ -94,6 +94,7 @@ SIGNATURES = [
     ('lcf_sampler_get_chain', C.c_int, [C.c_void_p, _dp, _dp]),
     ('lcf_sampler_reserve_chain', C.c_int, [C.c_void_p, C.c_int64]),
     ('lcf_sampler_get_naccepted', C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ('lcf_sampler_get_snapshot', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('lcf_sampler_last_run_ms', C.c_double, [C.c_void_p]),
     ('lcf_sampler_begin', C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, _ip, C.c_int32]),
     ('lcf_sampler_propose', C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
@@ -497,6 +498,14 @@ class NativeSampler:
         lp = np.empty((nsteps, self.nwalkers))
         _check(self._lib.lcf_sampler_get_chain(self._h, _ptr(chain), _ptr(lp)))
         return chain, lp
+
+    def snapshot(self):
+        """``(coords, log_prob, n_accepted)`` of the sampler's present state in one native call."""
+        x = np.empty((self.nwalkers, self.ndim))
+        lp = np.empty(self.nwalkers)
+        acc = np.empty(self.nwalkers, dtype=np.int64)
+        _check(self._lib.lcf_sampler_get_snapshot(self._h, x.ctypes.data, lp.ctypes.data, acc.ctypes.data))
+        return x, lp, acc
 
     def naccepted(self):
         out = np.empty(self.nwalkers, dtype=np.int64)

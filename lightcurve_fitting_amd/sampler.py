@@ -570,20 +570,21 @@ class EnsembleSampler:
         if self.randomize_split and self.nwalkers > 16384:  # beyond the device sort: host-generated colouring
             split = _rng.split_permutations(self.seed, self._steps_done, nsteps, self.nwalkers)
         self._in_flight = False
-        if self.collective == 'auto' and self._distributed():
+        distributed = self._distributed()      # (asked once: every question below used to ask torch.distributed again)
+        if self.collective == 'auto' and distributed:
             self._resolve_collective()
         try:
-            if self._distributed() and self.collective == 'rows' and self._peer_boards():
+            if distributed and self.collective == 'rows' and self._peer_boards():
                 import torch.distributed as dist
                 dist.barrier(group=self._group)  # every rank has returned from its previous run (see lcf_sampler_run_rows)
                 self._native.run_rows(self._steps_done, nsteps, split, store)
-            elif self._distributed() and self.collective == 'peers' and self._peer_mailboxes():
+            elif distributed and self.collective == 'peers' and self._peer_mailboxes():
                 import torch.distributed as dist
                 dist.barrier(group=self._group)  # every rank has returned from its previous run (see lcf_sampler_run_peers)
                 self._native.run_peers(self._steps_done, nsteps, split, store)
-            elif self._distributed() and self._native_comm() is not None:
+            elif distributed and self._native_comm() is not None:
                 self._native.run_sharded(self._comm, self._steps_done, nsteps, split, store)
-            elif self._distributed():
+            elif distributed:
                 ShardedStretchDriver(NativeBackend(self._native, rows=True), self._group,
                                      force_collective=self._force_sharded).run(self._steps_done, nsteps, split, store)
             elif asynchronous:
@@ -613,10 +614,9 @@ class EnsembleSampler:
             # The chain of a run stays in HBM until somebody reads it (or the next run needs the buffer): a run returns
             # when the device has finished, not when 80 bytes per walker and step have crossed PCIe.
             self._chain_on_device = nsteps
-        self._acc_seen = self._native.naccepted()
+        x, lp, self._acc_seen = self._native.snapshot()     # (state and counts: one trip through the binding)
         self._naccepted += self._acc_seen - self._acc0
         self._nsteps_counted += nsteps
-        x, lp = self._native.get_state()
         self._state = State(x, lp, None)
         return self._state
 

@@ -79,8 +79,8 @@ def test_config1_posterior_moments_against_a_long_oracle_chain():
 
 
 def test_config2_chain_at_the_benchmark_shape():
-    """CompanionShocking, 8000 points (four parts -> 1024-thread workgroups), 512 walkers x 2 steps against the
-    oracle-driven chain."""
+    """CompanionShocking, 8000 points (four parts -> 1024-thread workgroups, one proposal per CU: resident, k_solo_run<8, 1,
+    true, 8>), 512 walkers x 2 steps against the oracle-driven chain -- and the same chain from a launch per half-step."""
     model, lc, priors, lum0 = bench.build_companion(0)
     bands = [O.band(n) for n in lc['filter']]
     orc = O.CompanionShockingOracle(bands, lum0, z=0.003, variant=1)
@@ -92,15 +92,17 @@ def test_config2_chain_at_the_benchmark_shape():
     eng = model.engine_for(lc, priors=priors)
     x0 = bench.companion_walkers(512)
     s = EnsembleSampler(512, 8, eng, seed=bench.SEED)
-    assert s._native.set_half_step_kernel('auto') == 'solo'   # (four parts, one proposal per CU: 1024-thread workgroups)
+    assert s._native.set_half_step_kernel('auto') == 'run'   # (four parts, one proposal per CU: 1024-thread workgroups, resident)
     s.run_mcmc(x0, 2)
+    assert s._native.last_run_kernel() == 'run'
     ref, ref_lp, ref_acc = O.stretch_move_run(log_posterior, x0, 2, bench.SEED)
     assert relerr(s.get_chain(), ref) < 1e-9 and relerr(s.get_log_prob(), ref_lp) < 1e-9
     assert np.array_equal(np.round(s.acceptance_fraction * 2).astype(int), ref_acc)
-    f = EnsembleSampler(512, 8, eng, seed=bench.SEED)
-    f._native.set_half_step_kernel('fused')
-    f.run_mcmc(x0, 2)
-    assert np.array_equal(f.get_chain(), s.get_chain())
+    for kernel in ('fused', 'solo'):
+        f = EnsembleSampler(512, 8, eng, seed=bench.SEED)
+        assert f._native.set_half_step_kernel(kernel) == kernel
+        f.run_mcmc(x0, 2)
+        assert np.array_equal(f.get_chain(), s.get_chain())
 
 
 def test_config4_population_at_the_benchmark_shape():

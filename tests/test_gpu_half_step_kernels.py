@@ -447,8 +447,10 @@ def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
 
 
 def test_row_boards_companion_shape():
-    """The row boards with the companion model of configs[2]: 8 parameters, 8000 points in four parts, 1024-thread
-    workgroups (k_solo<8, 1, true, 4, BOARD>); two emulated ranks, 40 walkers, equal to the single-GPU run bit for bit."""
+    """The companion model of configs[2] -- 8 parameters, 8000 points in four parts -- at launches of at most one
+    workgroup per CU: 1024-thread workgroups, all four parts of a proposal side by side.  One chain, bit for bit, from
+    k_solo<8, 1, true, 8> (a launch per half-step), from the resident form k_solo_run<8, 1, true, 8> on one GPU, and from
+    two emulated ranks of a row-board run in either form."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -456,29 +458,40 @@ def test_row_boards_companion_shape():
     model, lc, priors, _ = bench.build_companion(0)
     nwalkers, nsteps = 40, 4
     x0 = bench.companion_walkers(nwalkers)
-    ref = NativeSampler(model.engine_for(lc, priors=priors), nwalkers, 9)
-    assert ref.set_half_step_kernel('auto') == 'solo'   # (four parts and 20 proposals: no resident workgroups)
+    eng = model.engine_for(lc, priors=priors)
+    ref = NativeSampler(eng, nwalkers, 9)
+    assert ref.set_half_step_kernel('solo') == 'solo'
     ref.set_state(x0)
     ref.run(0, nsteps, 'random', True)
     want_chain, want_lp = ref.get_chain()
-    # (a model keeps one engine per light curve: two models for the two ranks' engines)
-    engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
-    assert engines[0] is not engines[1]
-    samplers = [NativeSampler(e, nwalkers, 9) for e in engines]
-    ptrs = [s.board_export()[1] for s in samplers]
-    for r, s in enumerate(samplers):
-        s.board_connect(2, r, local_ptrs=ptrs)
-        s.set_state(x0)
-        s.run(100, nsteps, 'random', True)
-        s.set_state(x0)
-    for s in samplers:
-        s.run_rows(0, nsteps, 'random', True, asynchronous=True)
-    for s in samplers:
-        s.wait()
-    for s in samplers:
-        chain, lp = s.get_chain()
-        assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
-        assert np.array_equal(s.naccepted(), ref.naccepted())
+    one = NativeSampler(eng, nwalkers, 9)
+    assert one.set_half_step_kernel('auto') == 'run'    # (four parts and 20 proposals: resident 1024-thread workgroups)
+    one.set_state(x0)
+    one.run(0, nsteps, 'random', True)
+    assert one.last_run_kernel() == 'run'
+    chain, lp = one.get_chain()
+    assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp) and np.array_equal(one.naccepted(), ref.naccepted())
+    for form in ('resident', 'per half-step'):
+        # (a model keeps one engine per light curve: two models for the two ranks' engines)
+        engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
+        assert engines[0] is not engines[1]
+        samplers = [NativeSampler(e, nwalkers, 9) for e in engines]
+        ptrs = [s.board_export()[1] for s in samplers]
+        for r, s in enumerate(samplers):
+            s.board_connect(2, r, local_ptrs=ptrs)
+            s.set_state(x0)
+            s.run(100, nsteps, 'random', True)
+            s.set_state(x0)
+            s.set_half_step_kernel('auto' if form == 'resident' else 'solo')
+        for s in samplers:
+            s.run_rows(0, nsteps, 'random', True, asynchronous=True)
+        for s in samplers:
+            s.wait()
+            assert s.last_run_kernel() == ('run' if form == 'resident' else 'solo')
+        for s in samplers:
+            chain, lp = s.get_chain()
+            assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
+            assert np.array_equal(s.naccepted(), ref.naccepted())
 
 
 @pytest.mark.parametrize('form', ['resident', 'per half-step'])
