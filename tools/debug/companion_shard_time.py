@@ -1,27 +1,54 @@
-"""configs[2] as specified is STRONG scaling: 4096 walkers over N GPUs, i.e. 2048 / N proposals per rank and half-step.
-The row-board driver runs k_solo over a rank's own slots only, so one rank's launch at N GPUs is timed here, on one GPU,
-as the half-step of an ensemble of 4096 / N walkers (same kernel, same light curve; the board's polls and posts add the
-0.9 us measured for them in round 2).  Prints us per half-step launch and the strong-scaling factor it implies."""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
-import bench
-from lightcurve_fitting_amd.engine import NativeSampler
+"""What the 8-GPU scaling of the two sharded workloads comes to ON PAPER, from one GPU: per GPU count N, the time per
+half-step of ONE RANK of the row-board run -- a sampler connected as the only rank of such a run (its own uncached
+board, system-scope posts and polls, progress words, the row collection behind every launch) with as many proposals per
+half-step as a rank of an N-GPU run has -- against the single-GPU run of the whole ensemble.
 
-model, lc, priors, _ = bench.build_companion(0)
+  configs[2] (companion, default)   STRONG scaling: 4096 walkers over N GPUs, 2048 / N proposals per rank and half-step;
+                                    factor = t(1 GPU, 2048 proposals) / t(one rank, 2048 / N proposals)
+  configs[1] (`mcmc`)               WEAK scaling: 1024 walkers per GPU, 512 proposals per rank at any N;
+                                    factor = N x t(1 GPU, 512 proposals) / t(one rank, 512 proposals)
+
+What one GPU cannot show: the posts to the other N - 1 boards (one more 16-byte store per board and row, not waited
+for) and the fabric's share of the post -> poll latency.          python tools/debug/companion_shard_time.py [mcmc]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+import bench  # noqa: E402
+from lightcurve_fitting_amd.engine import NativeSampler  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else 'companion'
+if workload == 'companion':
+    model, lc, priors, _ = bench.build_companion(0)
+    walkers, total, steps = bench.companion_walkers, bench.COMPANION_WALKERS, 64
+else:
+    model, lc, priors = bench.build_problem(0)
+    walkers, total, steps = bench.initial_walkers, bench.WALKERS_PER_GPU, 640
 eng = model.engine_for(lc, priors=priors)
-base = None
-for n_gpus in (1, 2, 4, 8):
-    nw = bench.COMPANION_WALKERS // n_gpus
+
+
+def per_half_step(nw, rank):
     s = NativeSampler(eng, nw, 3)
-    s.set_state(bench.companion_walkers(nw))
-    s.run(0, 20, 'random', False)
+    if rank:
+        s.board_connect(1, 0, local_ptrs=[s.board_export()[1]])
+    s.set_state(walkers(nw))
+    run = s.run_rows if rank else s.run
+    run(0, 32, 'random', True)
     best = 1e9
     for rep in range(3):
-        s.run(20 + 60 * rep, 60, 'random', False)
-        best = min(best, s.last_run_ms() / 120)
-    if base is None:
-        base = best
-    print(f'{n_gpus} GPUs: {nw // 2:5d} proposals per rank and half-step ({s.last_run_kernel()}): {1e3 * best:8.2f} us per launch '
-          f'-> strong-scaling factor {base / best:5.2f} (+0.9 us of board traffic: {base / (best + 0.9e-3):5.2f})', flush=True)
+        run(32 + steps * rep, steps, 'random', True)
+        best = min(best, s.last_run_ms() / (2 * steps))
+    kernel, launches = s.last_run_kernel(), s.last_run_launches()
     s.close()
+    return 1e3 * best, kernel, launches
+
+
+t1, k1, _ = per_half_step(total, False)
+print(f'{workload}: 1 GPU, {total // 2} proposals per half-step ({k1}): {t1:.2f} us per half-step', flush=True)
+for n in (2, 4, 8):
+    nw = total // n if workload == 'companion' else total
+    t, k, launches = per_half_step(nw, True)
+    factor = t1 / t if workload == 'companion' else n * t1 / t
+    print(f'{n} GPUs: one rank with {nw // 2:5d} proposals per half-step ({k}, {launches} launches of the last run): {t:6.2f} us '
+          f'per half-step, row collection included -> {"strong" if workload == "companion" else "weak"}-scaling factor {factor:5.2f}',
+          flush=True)
