@@ -1075,9 +1075,9 @@ __device__ inline double mbox_take(const DevSampler& sm, long long g, int slot, 
 // split without communicating.
 // `slot_of` (or null): the slot table of k_slots, written here as well -- the step's two rows, and by the block's first
 // workgroup the row in front of the block (`front`, or all -1) -- so that the records need no launch in between.
-__global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, uint32_t key0, uint32_t key1,
-                                                    long long first_step, int* __restrict__ perm, int n_half,
-                                                    int* __restrict__ slot_of, const int* __restrict__ front) {
+__device__ __forceinline__ void make_perm_body(int n_walkers, int n_pad, uint32_t key0, uint32_t key1,
+                                               long long first_step, int* __restrict__ perm, int n_half,
+                                               int* __restrict__ slot_of, const int* __restrict__ front) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
     const long long step = first_step + blockIdx.x;
@@ -1127,6 +1127,28 @@ __global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, ui
     }
 }
 
+__global__ __launch_bounds__(1024) void k_make_perm(int n_walkers, int n_pad, uint32_t key0, uint32_t key1,
+                                                    long long first_step, int* __restrict__ perm, int n_half,
+                                                    int* __restrict__ slot_of, const int* __restrict__ front) {
+    make_perm_body(n_walkers, n_pad, key0, key1, first_step, perm, n_half, slot_of, front);
+}
+
+// Population mode: the same for MANY samplers in one launch (blockIdx.y = sampler; equal walker counts and blocks).  What
+// differs from sampler to sampler -- the key of its RNG, its buffers -- comes from an array in device memory.
+struct GenItem {
+    uint32_t key0, key1;
+    int* perm[2];
+    int* slot[2];
+    DrawRec* draws[2];
+};
+// `front_row` >= 0: the half-step in front of the block is row `front_row` of the OTHER buffer's slot table (-1: none)
+__global__ __launch_bounds__(1024) void k_make_perm_multi(const GenItem* __restrict__ items, int n_walkers, int n_pad,
+                                                          long long first_step, int buf, int n_half, long long front_row) {
+    const GenItem it = items[blockIdx.y];
+    make_perm_body(n_walkers, n_pad, it.key0, it.key1, first_step, it.perm[buf], n_half, it.slot[buf],
+                   front_row >= 0 ? it.slot[buf ^ 1] + (size_t)front_row * n_walkers : nullptr);
+}
+
 // Slot of every walker in each half-step of a block of steps (-1 where it is not active).  Rows of `slot_of`
 // ([1 + 2 n_steps][n_walkers]): row 0 = the half-step in front of the block (copied from the previous block, or all
 // -1 at the start of a run), row 1 + 2 k + half = half-step (k, half) of the block.
@@ -1148,8 +1170,8 @@ __global__ void k_slots(int n_walkers, int n_half, const int* __restrict__ perm,
 // moves in half 0 against the n_walkers - n_half walkers of colour 1, then colour 1 against colour 0 -- the larger
 // colour first, as emcee's red-blue split does for an odd ensemble; the slot an odd ensemble leaves empty in half 1
 // gets wid = -1.  `slot_of` null: no slot bookkeeping (the one-workgroup-per-proposal half-step does not need it).
-__global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* __restrict__ slot_of,
-                        long long first_step, long long n_steps, DrawRec* __restrict__ draws) {
+__device__ __forceinline__ void draws_body(const DevSampler& sm, const int* __restrict__ perm, const int* __restrict__ slot_of,
+                                           long long first_step, long long n_steps, DrawRec* __restrict__ draws) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_steps * 2 * sm.n_half) return;
     const int i = (int)(idx % sm.n_half), half = (int)((idx / sm.n_half) & 1);
@@ -1199,6 +1221,19 @@ __global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* 
         }
     }
     draws[idx] = d;
+}
+
+__global__ void k_draws(DevSampler sm, const int* __restrict__ perm, const int* __restrict__ slot_of,
+                        long long first_step, long long n_steps, DrawRec* __restrict__ draws) {
+    draws_body(sm, perm, slot_of, first_step, n_steps, draws);
+}
+// (population mode, blockIdx.y = sampler: `sm` = the samplers' common shape, the key from the item)
+__global__ void k_draws_multi(const GenItem* __restrict__ items, DevSampler sm, int buf, long long first_step,
+                              long long n_steps) {
+    const GenItem it = items[blockIdx.y];
+    sm.key0 = it.key0;
+    sm.key1 = it.key1;
+    draws_body(sm, it.perm[buf], it.slot[buf], first_step, n_steps, it.draws[buf]);
 }
 
 // The serial part of a half-step for slot i, executed by ONE wave (lane = 0..63): accept tests of the previous
@@ -2905,7 +2940,9 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     int *dfilt, *dorig;
     double2* dtab;
     PriorDev* dpri = nullptr;
-#define UP(h, d) if ((st = upload(h, &d, e->owned)) != LCF_OK) return bail(st)
+    // (one block, one copy: the photometry in its layouts, the tables and the staging image; sized for the light curve)
+    UploadArena arena(e->owned, (size_t)256 * 1024 + (size_t)N * 256);
+#define UP(h, d) if ((st = upload(h, &d, arena)) != LCF_OK) return bail(st)
     UP(ht, dt); UP(hy, dy_); UP(hdy, ddy); UP(hfilt, dfilt); UP(horig, dorig);
     UP(htab, dtab); UP(htaboff, e->d_tab_off);
     if (reddened) {
@@ -3019,6 +3056,7 @@ lcf_status lcf_engine_create(const lcf_problem* pr, int32_t device, lcf_engine**
     dp.t = dt; dp.y = dy_; dp.dy = ddy; dp.pt_filt = dfilt; dp.pt_orig = dorig;
     dp.tab = dtab;
     dp.knots = dkn; dp.spl = dspl; dp.priors = dpri;
+    if ((st = arena.flush()) != LCF_OK) return bail(st);
     if ((st = e->sync_dp()) != LCF_OK) return bail(st);
     *out = e;
     return LCF_OK;
@@ -3969,8 +4007,9 @@ lcf_status reserve_chain(lcf_sampler* s, int64_t n_steps) {
 // `need_slots`: the draw records carry each walker's slot in the previous half-step (every path except k_solo).
 // `gen`: the stream the first block of draw records is generated on (default: the engine's own -- where a single
 // sampler's half-steps follow; a population's half-steps all run on ONE stream, and so do its samplers' records).
+// `defer`: the first block is NOT generated here (a population generates the blocks of all its samplers in one launch).
 lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode, const int32_t* perm,
-                         int32_t store_chain, bool need_slots, hipStream_t gen = nullptr) {
+                         int32_t store_chain, bool need_slots, hipStream_t gen = nullptr, bool defer = false) {
     if (!s || n_steps < 0 || first_step < 0) return fail(LCF_ERR_INVALID_ARGUMENT, "bad argument");
     if (split_mode < LCF_SPLIT_IDENTITY || split_mode > LCF_SPLIT_HOST)
         return fail(LCF_ERR_INVALID_ARGUMENT, "bad split_mode");
@@ -4045,13 +4084,14 @@ lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, in
     }
     s->blk_steps = s->blk_cap;
     s->blk_first = std::min<int64_t>(s->blk_cap, LCF_FIRST_BLOCK);
-    if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown &&
+    if (s->spec_first == first_step && s->spec_mode == split_mode && s->spec_slots == need_slots && !grown && !defer &&
         (gen == nullptr || gen == e->stream)) {   // (a block speculated on the engine's stream is not ordered with another)
         s->spec_first = -1;  // the previous run left this run's first block behind (speculate_continuation)
         s->blk_generated = 0;
         return LCF_OK;
     }
     s->spec_first = -1;
+    if (defer) return LCF_OK;
     return generate_block(s, 0, gen ? gen : e->stream);
 }
 
@@ -4826,9 +4866,70 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     hipStream_t pop_stream = s0->e->stream;
     long long g = 0;
     for (int t = 0; t < n; ++t) {
-        if (lcf_status st = sampler_begin(ss[t], first_step, n_steps, split_mode, nullptr, store_chain, true, pop_stream)) return st;
+        if (lcf_status st = sampler_begin(ss[t], first_step, n_steps, split_mode, nullptr, store_chain, true, pop_stream,
+                                          /*defer: see pop_generate*/ true)) return st;
         g = std::max(g, ss[t]->g_next);
     }
+    // The draw records of ALL transients come from one launch of each generation kernel per block of steps (random
+    // splits of samplers with the same block geometry -- what a population has; else sampler by sampler as before).
+    bool batched_gen = split_mode == LCF_SPLIT_RANDOM;
+    for (int t = 1; t < n; ++t)
+        batched_gen = batched_gen && ss[t]->blk_first == s0->blk_first && ss[t]->blk_steps == s0->blk_steps;
+    GenItem* dgen = nullptr;
+    if (batched_gen) {
+        std::vector<GenItem> gen(n);
+        for (int t = 0; t < n; ++t)
+            gen[t] = GenItem{ss[t]->ds.key0, ss[t]->ds.key1, {ss[t]->d_perm[0], ss[t]->d_perm[1]},
+                             {ss[t]->d_slot[0], ss[t]->d_slot[1]}, {ss[t]->d_draws[0], ss[t]->d_draws[1]}};
+        LCF_HIP(hipMalloc((void**)&dgen, (size_t)n * sizeof(GenItem)));
+        if (hipMemcpy(dgen, gen.data(), (size_t)n * sizeof(GenItem), hipMemcpyHostToDevice) != hipSuccess) {
+            hipFree(dgen);
+            return fail(LCF_ERR_HIP, "hipMemcpy of the generation items");
+        }
+    }
+    // block b of every sampler (enqueued on the population's stream)
+    auto pop_generate = [&](int64_t b) -> lcf_status {
+        if (!batched_gen) {
+            for (int t = 0; t < n; ++t)
+                if (lcf_status r = generate_block(ss[t], b, pop_stream)) return r;
+            return LCF_OK;
+        }
+        const DevSampler& d0 = s0->ds;
+        const int buf = (int)(b & 1);
+        const int64_t k0 = s0->block_start(b), len = s0->block_len(b);
+        int n_pad = 2;
+        while (n_pad < d0.n_walkers) n_pad <<= 1;
+        const int threads = std::min(1024, std::max(64, n_pad / 2));
+        const long long front_row = b > 0 ? 2 * (long long)s0->block_len(b - 1) : -1;
+        if ((size_t)n_pad * 8 > 65536)
+            LCF_HIP(hipFuncSetAttribute((const void*)k_make_perm_multi, hipFuncAttributeMaxDynamicSharedMemorySize, n_pad * 8));
+        hipLaunchKernelGGL(k_make_perm_multi, dim3((unsigned)len, (unsigned)n), dim3(threads), (size_t)n_pad * 8, pop_stream, dgen,
+                           d0.n_walkers, n_pad, (long long)(s0->run_first + k0), buf, d0.n_half, front_row);
+        const long long recs = (long long)len * 2 * d0.n_half;
+        hipLaunchKernelGGL(k_draws_multi, dim3((unsigned)((recs + 255) / 256), (unsigned)n), dim3(256), 0, pop_stream, dgen, d0,
+                           buf, (long long)(s0->run_first + k0), (long long)len);
+        LCF_HIP(hipGetLastError());
+        for (int t = 0; t < n; ++t) ss[t]->blk_generated = b;
+        return LCF_OK;
+    };
+    auto pop_enter = [&](long long rel) -> lcf_status {      // (enter_half_step for all samplers)
+        const int64_t b = s0->block_of_step(rel / 2);
+        if (b == s0->blk_current) return LCF_OK;
+        while (s0->blk_generated < b)
+            if (lcf_status r = pop_generate(s0->blk_generated + 1)) return r;
+        for (int t = 0; t < n; ++t) ss[t]->blk_current = b;
+        return LCF_OK;
+    };
+    auto pop_leave = [&]() -> lcf_status {                    // (leave_half_step for all samplers)
+        const int64_t last = s0->block_of_step(s0->run_steps - 1);
+        if (s0->blk_generated == s0->blk_current && s0->blk_current < last) return pop_generate(s0->blk_current + 1);
+        return LCF_OK;
+    };
+    if (n_steps > 0)
+        if (lcf_status r = pop_generate(0)) {
+            if (dgen) hipFree(dgen);
+            return r;
+        }
     std::vector<MultiItem> items(n);
     size_t lds = 0;
     int max_parts = 1;
@@ -4893,8 +4994,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     if (one_launch) {
         const dim3 gq((unsigned)((nh + pop_group - 1) / pop_group), (unsigned)n), bq(64 * pop_group);
         for (int64_t k = 0; k < 2 * n_steps && err == hipSuccess; ++k) {
-            for (int t = 0; t < n && err == hipSuccess; ++t)
-                if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
+            if (pop_enter(k) != LCF_OK) err = hipErrorUnknown;
             if (err != hipSuccess) break;
 #define LCF_POP3(ND, G, M) do { allow_lds(k_pop<ND, 1, G, M>, pop_lds);                                             \
                                 hipLaunchKernelGGL((k_pop<ND, 1, G, M>), gq, bq, pop_lds, st, ditems, (long long)k); } while (0)
@@ -4914,19 +5014,16 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
 #undef LCF_POP2
 #undef LCF_POP3
 #undef LCF_POP
-            for (int t = 0; t < n && err == hipSuccess; ++t) {
+            for (int t = 0; t < n; ++t)
                 if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
-                if (leave_half_step(ss[t], st) != LCF_OK) err = hipErrorUnknown;
-            }
+            if (err == hipSuccess && pop_leave() != LCF_OK) err = hipErrorUnknown;
             if (err == hipSuccess) err = hipGetLastError();
         }
     }
     for (int64_t k = 0; !one_launch && k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
-        if (have_next)  // every transient's block of draw records resident for this stream
-            for (int t = 0; t < n && err == hipSuccess; ++t)
-                if (enter_half_step(ss[t], k, st) != LCF_OK) err = hipErrorUnknown;
+        if (have_next && pop_enter(k) != LCF_OK) err = hipErrorUnknown;   // (every transient's block of draw records)
         if (err != hipSuccess) break;
 #define LCF_STEPM(ND) hipLaunchKernelGGL(k_step_multi<ND>, gs, bs, 0, st, ditems, have_prev ? 1 : 0,                      \
                                          (long long)((k - 1) / 2), have_next ? 1 : 0, (long long)k, (long long)(g + k))
@@ -4940,11 +5037,11 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             default: LCF_STEPM(0); break;
         }
 #undef LCF_STEPM
-        if (have_next)
-            for (int t = 0; t < n && err == hipSuccess; ++t) {
+        if (have_next) {
+            for (int t = 0; t < n; ++t)
                 if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
-                if (leave_half_step(ss[t], st) != LCF_OK) err = hipErrorUnknown;
-            }
+            if (err == hipSuccess && pop_leave() != LCF_OK) err = hipErrorUnknown;
+        }
         if (!have_next) break;
         const int parity = (int)((g + k) & 1);
 #define LCF_PM(V, L, T) do { allow_lds(k_points_multi<V, L, T>, lds);                                       \
@@ -4970,6 +5067,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     }
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     hipFree(ditems);
+    if (dgen) hipFree(dgen);
     LCF_HIP(err);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && elapsed_ms) *elapsed_ms = ms;

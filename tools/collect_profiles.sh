@@ -18,6 +18,8 @@ declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
 declare -A PSTEPS=( [mcmc]=64 [companion]=2 [population]=3 [sed]=1 )   # (mcmc: two launches of 64 half-steps)
 declare -A KERNEL=( [mcmc]=k_solo_run [companion]=k_solo [population]=k_pop [sed]=k_sed_interp )
 declare -A PTAG=( [mcmc]=k_solo_run_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
+# (the profiled bench runs must stay ONE process each: the end-to-end block of the headline line starts a child)
+export LCF_BENCH_NO_E2E=1
 for W in mcmc companion population sed; do
   echo "== $W: kernel trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 $R/bench.py --workload $W --steps ${STEPS[$W]} --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof_$W.json 2> $OUT/trace_$W.log \
@@ -55,6 +57,7 @@ PY
   [ $? -eq 0 ] || FAILED=1
 done
 echo "== unprofiled bench lines"
+unset LCF_BENCH_NO_E2E
 cd $R
 mkdir -p profiles && cp $FINAL/${TAG}_pmc_*.json profiles/ 2>/dev/null
 for W in mcmc companion population sed; do
