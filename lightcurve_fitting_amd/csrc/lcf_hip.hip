@@ -3824,19 +3824,24 @@ lcf_status rows_image(lcf_sampler* s, hipStream_t st, const DevSampler** out) {
 // Half-steps [rel, rel + n_hs) of the run, all inside the current block of draw records.
 // `ranks`: this rank's slots [lo, hi) only, rows between the ranks' boards (lcf_sampler_run_rows); `need_progress`: see
 // k_solo_run<..., RANKS>.
+// `dry`: nothing is launched -- the kernel the launch would take is resolved, its LDS attribute set and its capacity on this
+// device asked (what a process pays ONCE per kernel: lcf_sampler_board_connect does it ahead of the first run, so that no
+// rank's first launch makes such calls while another rank's resident workgroups already wait for it).
 lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st, bool ranks = false, int lo = 0, int hi = 0,
-                      long long need_progress = 0) {
+                      long long need_progress = 0, bool dry = false) {
     lcf_engine* e = s->e;
     const DevSampler* rs = nullptr;
     int run_flags = 0;
-    if (ranks) {
+    if (dry) {
+        if (!ranks) hi = s->ds.n_half;
+    } else if (ranks) {
         if (lcf_status r = rows_image(s, st, &rs)) return r;
     } else {
         if (lcf_status r = run_image(s, st, &rs, &run_flags)) return r;
         lo = 0;
         hi = s->ds.n_half;
     }
-    const DrawRec* draws = s->rows(rel);
+    const DrawRec* draws = dry ? nullptr : s->rows(rel);
     const size_t lds = solo_lds_bytes(e);
     const long long g_run0 = s->g_run0;
     const long long state_from = 2 * (s->run_steps - 1);   // X / LP / counts: written by the run's last step
@@ -3850,6 +3855,7 @@ lcf_status launch_run(lcf_sampler* s, long long rel, int n_hs, hipStream_t st, b
         if (lcf_status r = run_capacity(s, k_solo_run<ND, 1, true, NP, M, R>, kThr, lds)) return r;                   \
         const int cap = NP == 8 ? s->run_capacity_wide : s->run_capacity;                                             \
         if (cap < 1) return fail(LCF_ERR_UNSUPPORTED, "k_solo_run does not fit the device");                          \
+        if (dry) break;                                                                                               \
         const int n_wg = std::min(hi - lo, cap);                                                                      \
         const dim3 grid((unsigned)(test_missing && n_wg > 1 ? n_wg - 1 : n_wg));                                      \
         arrivals += (unsigned int)n_wg;   /* (0 = "no check": skipped when the count wraps onto it) */                 \
@@ -4656,6 +4662,17 @@ lcf_status lcf_sampler_board_connect(lcf_sampler* s, int32_t n_ranks, int32_t ra
     }
     s->ds.n_board_ranks = n_ranks;
     s->ds.board_rank = rank;
+    // (the kernel a resident run of this rank will take, resolved now: see launch_run's `dry`; and the image of the
+    // sampler it reads, allocated now: an allocation made by one rank of a process while another rank's resident
+    // workgroups already wait for it can hold its launch back for seconds)
+    if (!s->d_rows_image) {
+        LCF_HIP(hipMalloc((void**)&s->d_rows_image, sizeof(DevSampler)));
+        s->owned.push_back(s->d_rows_image);
+        s->rows_image_valid = false;
+    }
+    const int width = s->ds.n_half / n_ranks;
+    if (rows_resident_eligible(s, width))
+        if (lcf_status st = launch_run(s, 0, 0, s->e->stream, true, rank * width, rank * width + width, 0, true)) return st;
     return LCF_OK;
 }
 
@@ -4672,7 +4689,15 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
     if (s->ds.n_board_ranks < 1) return fail(LCF_ERR_STATE, "lcf_sampler_board_connect must be called first");
     if (!solo_eligible(s))
         return fail(LCF_ERR_UNSUPPORTED, "row-board runs need the one-workgroup-per-proposal half-step (k_solo)");
+    static const bool trace = std::getenv("LCF_TRACE_RUN") != nullptr;   // (diagnostic: host time of the enqueue's parts)
+    const auto t_in = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (trace)
+            std::fprintf(stderr, "lcf_sampler_run_rows (rank %d): %s at %.1f us\n", s->ds.board_rank, what,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count());
+    };
     if (lcf_status st = sampler_begin(s, first_step, n_steps, split_mode, perm, store_chain, true)) return st;
+    mark("draw records enqueued");
     hipStream_t st = s->e->stream;
     DevSampler& ds = s->ds;
     const int width = ds.n_half / ds.n_board_ranks, lo = ds.board_rank * width, hi = lo + width;
@@ -4701,6 +4726,7 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
             const int n = (int)std::min<long long>(kRunSpan, end - rel);
             const long long need = starts[0] >= 0 ? s->g_run0 + starts[0] : 0;
             if (lcf_status r = launch_run(s, rel, n, st, true, lo, hi, need)) return r;
+            mark("resident launch enqueued");
             if (store_chain) {
                 hipLaunchKernelGGL(k_board_collect, dim3((unsigned)n * collect_blocks), dim3(256), 0, st, ds,
                                    (long long)(s->g_run0 + rel), (long long)(rel / 2), s->rows(rel), n, 0, 1);
@@ -4729,7 +4755,9 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
     }
     s->g_next += 2 * n_steps;
     LCF_HIP(hipEventRecord(s->ev1, st));
-    return enqueue_snapshot(s);
+    const lcf_status rc = enqueue_snapshot(s);
+    mark("all enqueued");
+    return rc;
 }
 
 lcf_status lcf_sampler_run_rows(lcf_sampler* s, int64_t first_step, int64_t n_steps, int32_t split_mode,
