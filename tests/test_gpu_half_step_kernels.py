@@ -319,14 +319,17 @@ def test_row_boards_emulated_ranks(ranks, nwalkers, split, form):
         assert np.array_equal(x, want_x) and np.array_equal(lp_end, want_lp_end)
 
 
-@pytest.mark.parametrize('ranks,nwalkers,block', [(2, 40, None), (3, 36, '5')])
-def test_resident_row_boards_across_launches_and_draw_blocks(ranks, nwalkers, block, monkeypatch):
+@pytest.mark.parametrize('ranks,nwalkers,block,grid', [(2, 40, None, None), (3, 36, '5', None), (2, 44, None, '4')])
+def test_resident_row_boards_across_launches_and_draw_blocks(ranks, nwalkers, block, grid, monkeypatch):
     """A row-board run of 150 steps with resident workgroups: five launches per rank (32 steps each; every launch from the
     third on waits for the other ranks' progress words), the seam between the first block of draw records and the next --
-    and, with blocks of 5 steps, thirty launches of ten half-steps.  Chain, state and counts of every rank equal the
-    single-GPU run's."""
+    and, with blocks of 5 steps, thirty launches of ten half-steps; with four resident workgroups per rank (LCF_RUN_GRID)
+    for its eleven slots of a half-step, every workgroup takes two or three of them in turn.  Chain, state and counts of
+    every rank equal the single-GPU run's."""
     if block:
         monkeypatch.setenv('LCF_DRAW_BLOCK', block)
+    if grid:
+        monkeypatch.setenv('LCF_RUN_GRID', grid)
     pb, eng = _multiband()
     nsteps = 150
     x0 = pb['truth'] * (1 + 0.05 * np.random.default_rng(14).standard_normal((nwalkers, 5)))
