@@ -1642,25 +1642,30 @@ __global__ void k_board_init(const DevSampler sm, unsigned int tag) {
 }
 
 // The rows of half-step G, as every rank posted them, into this rank's state (end of a run: `n_hs` = 2, the last step)
-// and / or into the chain (`to_chain`, every half-step of a run that stores it).  One wave per slot, lane = column.
+// and / or into the chain (`to_chain`, every half-step of a run that stores it).  A wave takes as many slots as whole rows
+// fit its 64 lanes (8 rows of 8 entries for up to six parameters), lane = (row, column): behind a resident launch of an
+// 8-GPU run there are 64 x 4096 rows to collect, and a wave per row left 57 of 64 lanes idle on a kernel that is nothing
+// but round trips to uncached memory (33 us per 131 k rows; 0.25 ns per row).
 __global__ void k_board_collect(const DevSampler sm, long long G, long long row, const DrawRec* __restrict__ draws, int n_hs,
                                 int to_state, int to_chain) {
-    const int lane = threadIdx.x & 63, nd = sm.n_dim;
-    const long long item = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (item >= (long long)n_hs * sm.n_half) return;
+    const int nd = sm.n_dim, re = board_row_entries(nd), rpw = 64 / re;   // rows per wave (kMaxDim + 2 <= 24 entries: >= 2)
+    const int lane = threadIdx.x & 63, sub = lane / re, col = lane - sub * re;
+    const long long wave = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const long long item = wave * rpw + sub;
+    if (sub >= rpw || item >= (long long)n_hs * sm.n_half) return;
     const int h = (int)(item / sm.n_half);
     const DrawRec dr = draws[item];
-    if (dr.wid < 0 || lane > nd + 1) return;
+    if (dr.wid < 0 || col > nd + 1) return;
     if (board_aborted(sm)) return;
-    const double v = board_take(sm, (unsigned int)(G + h + 1), dr.wid, lane);
+    const double v = board_take(sm, (unsigned int)(G + h + 1), dr.wid, col);
     if (to_state) {
-        if (lane < nd) sm.X[(size_t)dr.wid * nd + lane] = v;
-        else if (lane == nd) sm.LP[dr.wid] = v;
+        if (col < nd) sm.X[(size_t)dr.wid * nd + col] = v;
+        else if (col == nd) sm.LP[dr.wid] = v;
         else sm.nacc[dr.wid] = (long long)v;
     }
     if (to_chain && sm.store_chain) {
-        if (lane < nd) sm.chain[((size_t)(row + h / 2) * sm.n_walkers + dr.wid) * nd + lane] = v;
-        else if (lane == nd) sm.chain_lp[(size_t)(row + h / 2) * sm.n_walkers + dr.wid] = v;
+        if (col < nd) sm.chain[((size_t)(row + h / 2) * sm.n_walkers + dr.wid) * nd + col] = v;
+        else if (col == nd) sm.chain_lp[(size_t)(row + h / 2) * sm.n_walkers + dr.wid] = v;
     }
 }
 
@@ -4711,7 +4716,9 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
                        (unsigned int)s->g_run0);
     LCF_HIP(hipGetLastError());
     s->rows_arrivals = 0;   // (k_board_init has cleared the word)
-    const unsigned collect_blocks = (unsigned)((ds.n_half + 3) / 4);
+    // (k_board_collect: workgroups of four waves, each wave 64 / board_row_entries rows)
+    const int collect_rpw = 64 / board_row_entries(ds.n_dim);
+    auto collect_grid = [&](long long rows) { return dim3((unsigned)((rows + 4 * collect_rpw - 1) / (4 * collect_rpw))); };
     if (resident) {
         // The rank's workgroups stay for a block of up to kRunSpan half-steps (k_solo_run<..., RANKS>); behind every launch
         // the rows of its half-steps -- as every rank posted them -- go from the board into the chain, behind the last one
@@ -4728,7 +4735,7 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
             if (lcf_status r = launch_run(s, rel, n, st, true, lo, hi, need)) return r;
             mark("resident launch enqueued");
             if (store_chain) {
-                hipLaunchKernelGGL(k_board_collect, dim3((unsigned)n * collect_blocks), dim3(256), 0, st, ds,
+                hipLaunchKernelGGL(k_board_collect, collect_grid((long long)n * ds.n_half), dim3(256), 0, st, ds,
                                    (long long)(s->g_run0 + rel), (long long)(rel / 2), s->rows(rel), n, 0, 1);
                 LCF_HIP(hipGetLastError());
             }
@@ -4741,7 +4748,7 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
         for (int64_t k = 0; k < 2 * n_steps; ++k) {
             if (lcf_status r = launch_solo(s, k, st, true, lo, hi)) return r;
             if (store_chain && (k & 1)) {  // the rows of this step's two half-steps, from every rank, into the chain
-                hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds,
+                hipLaunchKernelGGL(k_board_collect, collect_grid(2ll * ds.n_half), dim3(256), 0, st, ds,
                                    (long long)(s->g_run0 + k - 1), (long long)(k / 2), s->rows(k - 1), 2, 0, 1);
                 LCF_HIP(hipGetLastError());
             }
@@ -4749,7 +4756,7 @@ lcf_status lcf_sampler_run_rows_async(lcf_sampler* s, int64_t first_step, int64_
     }
     if (n_steps > 0) {  // the last step's rows of all walkers into X / LP / counts
         const long long k = 2 * (n_steps - 1);
-        hipLaunchKernelGGL(k_board_collect, dim3(2 * collect_blocks), dim3(256), 0, st, ds, (long long)(s->g_run0 + k),
+        hipLaunchKernelGGL(k_board_collect, collect_grid(2ll * ds.n_half), dim3(256), 0, st, ds, (long long)(s->g_run0 + k),
                            (long long)(k / 2), s->rows(k), 2, 1, 0);
         LCF_HIP(hipGetLastError());
     }
