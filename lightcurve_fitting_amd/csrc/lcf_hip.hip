@@ -2305,7 +2305,6 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
     constexpr int kD = ND > 0 ? ND : kMaxDim;
     const int nd = ND > 0 ? ND : sm.n_dim;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid, kThreads);
     {
         // ---- the serial heads, one per wave, side by side
         double* sc = scratch + wave * kPopScratch;
@@ -2315,11 +2314,12 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
         DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0, 0};
         if (slot < nh) dr = item_rows(it, rel)[slot];     // wave-uniform
         const bool active = dr.wid >= 0;  // (an odd ensemble's smaller colour leaves its last slot empty)
-        if (active) {
-            HeadRows<ND> rows;
-            head_fetch<ND>(pb, sm, dr, lane, rows);
-            proposal_head<ND, false, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
-        }
+        // (the rows are requested first, the tables staged while they are on their way: a launch per half-step pays the
+        // staging every time, and in front of the heads it was a round trip of its own)
+        HeadRows<ND> rows;
+        if (active) head_fetch<ND>(pb, sm, dr, lane, rows);
+        stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid, kThreads);
+        if (active) proposal_head<ND, false, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
         if (lane == 0) {
             if (!active) sc[kNCoef] = -INFINITY;
             sx[kMaxDim + 1] = dr.zl;
@@ -2351,7 +2351,8 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
             if (lane == 0) red[(w * kPopMaxParts + part) * 4 + v] = ws;
         }
     }
-    __syncthreads();
+    // (no barrier here: u = wave (mod GROUP), so a wave has walked the units of ITS proposal only -- the sums it reads
+    // below are the ones its own lane 0 wrote, and a wave's LDS operations execute in order)
     if (lane != 0) return;
     // ---- accept / reject and commit (models.py:121-135 -> fitting.py:121-128 -> emcee's stretch move), one lane per proposal
     const double* sc = scratch + wave * kPopScratch;
