@@ -363,7 +363,7 @@ def committed_pmc(tag):
 
 
 def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_quad, peak, alg_instr_per_eval,
-                   alg_bytes_per_eval, pmc_tag, waves_per_launch=None, interp=None):
+                   alg_bytes_per_eval, pmc_tag, waves_per_launch=None, interp=None, hs_per_launch=None):
     """`achieved` / `frac`: lane-instructions of the band-sum loop the shipped algorithm executes per second, against
     the vector-ALU issue peak -- a lower bound of what the kernel issues.  `interp` = (points, epochs) per evaluation on
     the interpolated path (variant 3), counted at their own instruction counts; `quads_per_eval` then covers only the
@@ -404,7 +404,9 @@ def roofline_block(kernel, kern_ms, evals_per_launch, quads_per_eval, valu_per_q
         out['executed_pmc'] = None
         out['pmc_note'] = why
         return out
-    c = {k: v['mean_per_launch'] for k, v in doc['counters'].items()}
+    # (resident launches: the profiled launches may cover another number of half-steps than this run's -- scaled per half-step)
+    scale = hs_per_launch / doc['half_steps_per_launch'] if hs_per_launch and doc.get('half_steps_per_launch') else 1.
+    c = {k: v['mean_per_launch'] * (1. if k == 'SQ_WAVES' else scale) for k, v in doc['counters'].items()}
     # FETCH_SIZE is doubled as the gfx950 correction for 16-B-per-lane coalesced reads prescribes (MI355X_MICROARCH.md,
     # HBM section); both counters are in KiB
     out['traffic'] = (2. * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024. if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c else None
@@ -853,12 +855,18 @@ def run_population(args):
         used = pop[pop.indices[0]]._native.last_run_kernel()
         name = {'population': 'k_pop<5,1,4> (ONE launch per half-step for all 32 transients of this GPU: a workgroup per '
                               'four proposals, serial heads side by side, accept test included)',
+                'population-run': 'k_pop_run<5,1,4> (the workgroups of all 32 transients of this GPU stay for blocks of up to 64 '
+                                  'half-steps: 4 proposals at a time each, rows handed over through the transients\' boards of '
+                                  'tagged rows, tables and interpolants staged in LDS once per launch; time per HALF-STEP)',
                 'population-phases': 'k_step_multi + k_points_multi (the two launches of a half-step of all 32 '
                                      'transients of this GPU; the likelihood launch dominates)'}[used]
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
-        roof = roofline_block(name, pair_ms, 32 * nw // 2, quads, None, PEAK_FP64_TINSTR, alg_instr, ALG_BYTES,
-                              'population' if (used, args.variant) == ('population', 3) else f'{used}_v{args.variant}',
-                              interp=(n_interp, 100) if n_interp else None)
+        launches = pop[pop.indices[0]]._native.last_run_launches() if used == 'population-run' else 2 * args.steps
+        hs_per_launch = 2 * args.steps / launches       # (resident launches: blocks of up to 64 half-steps)
+        roof = roofline_block(name, pair_ms * hs_per_launch, int(32 * nw // 2 * hs_per_launch), quads, None, PEAK_FP64_TINSTR,
+                              alg_instr, ALG_BYTES,
+                              'population' if (used, args.variant) == ('population-run', 3) else f'{used}_v{args.variant}',
+                              interp=(n_interp, 100) if n_interp else None, hs_per_launch=hs_per_launch)
         out = {'metric': 'walker-steps/sec (population of independent ensembles)',
                'value': n_tr * nw * args.steps / elapsed, 'unit': 'walker-steps/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -868,6 +876,8 @@ def run_population(args):
                           'transients': n_tr, 'walkers_per_transient': nw, 'points': 600,
                           'planck_samples_executed_per_eval': 4 * quads},
                'roofline': roof, 'device_ms_per_step': pop.last_run_ms / args.steps}
+        roof['half_steps_per_launch'] = hs_per_launch
+        roof['kernel_ms_per_half_step'] = pair_ms
         if world == 1 and not args.no_cpu_baseline:
             from oracle import lcf_oracle as O
             bands = [O.band(n) for n in first_lc['filter']]

@@ -236,7 +236,8 @@ lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int3
  * launches, k_fused, k_solo; for lcf_population_run one launch per half-step for all transients (k_pop: a workgroup per
  * four proposals, accept test included) or the two launches k_step_multi + k_points_multi. */
 enum { LCF_KERNEL_PHASES = 0, LCF_KERNEL_FUSED = 1, LCF_KERNEL_SOLO = 2, LCF_KERNEL_POPULATION = 3,
-       LCF_KERNEL_POPULATION_PHASES = 4, LCF_KERNEL_RUN = 5 /* k_solo_run: a block of half-steps per launch */ };
+       LCF_KERNEL_POPULATION_PHASES = 4, LCF_KERNEL_RUN = 5 /* k_solo_run: a block of half-steps per launch */,
+       LCF_KERNEL_POPULATION_RUN = 6 /* k_pop_run: the same for all transients of a population */ };
 int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s);
 /* Launches of that kernel in the last single-GPU run (lcf_sampler_run / _run_async): two per step, or -- k_solo_run --
  * one per block of up to 32 steps. */

@@ -2236,6 +2236,13 @@ struct MultiItem {
     long long blk_first, blk_steps; // steps in block 0 / in every later block
     double* coef;
     double* lprior;
+    // resident population launches (k_pop_run): the transient's board is sm.board; `flip`: its start state is in
+    // sm.X_out / LP_out / nacc_out; `arrive0`: its board's count of started workgroups before this run; `itab_extra`:
+    // doubles of pb.itab the launch stages in LDS itself, behind the image (the engine's image has them only for long
+    // light curves -- a launch per half-step cannot afford 24 KiB more per workgroup, a launch per 32 steps can)
+    long long g_run0;
+    int flip, itab_extra;
+    unsigned int arrive0, pad;
 };
 
 // Draw records of a transient's half-step `rel` of the run (the host keeps that block resident).
@@ -2278,6 +2285,10 @@ __global__ __launch_bounds__(kBlock) void k_points_multi(const MultiItem* __rest
 // transient's DevProblem is read through a constant-address-space pointer: scalar loads, as kernel arguments are.
 constexpr int kPopScratch = kSoloScratch + 6;   // doubles per proposal: k_solo's + (ln z term, ln u, walker id), padded
 constexpr int kPopMaxParts = 4;
+#ifndef LCF_POP_RUN_GROUP
+#define LCF_POP_RUN_GROUP 4
+#endif
+constexpr int kPopRunGroup = LCF_POP_RUN_GROUP;   // proposals (= waves) per workgroup of the resident form (k_pop_run)
 
 #ifndef LCF_POP_WAVES
 #define LCF_POP_WAVES LCF_WAVES
@@ -2385,6 +2396,152 @@ __global__ __launch_bounds__(64 * GROUP, LCF_POP_WAVES) void k_pop(const MultiIt
         for (int d = 0; d < kD; ++d)
             if (d < nd) crow[d] = ok ? sq[d] : sx[d];
         sm.chain_lp[(size_t)row * sm.n_walkers + wid] = ok ? nlp : lp_i;
+    }
+}
+
+// What one lane of a wave wrote to LDS, read by the wave's other lanes WITHOUT a workgroup barrier in between: the hardware
+// executes a wave's LDS operations in order, but the compiler sees one thread -- it may move a load of sc[k] in front of
+// `if (lane == 0) sc[k] = ...` for the lanes that do not store.  A fence at wavefront scope costs no instruction and keeps
+// the order of the program.
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- population mode with RESIDENT workgroups ------------------------------------------------------------------------
+// k_pop's half-step in a loop over up to kRunSpan half-steps, as k_solo_run is k_solo's: gridDim.y = transient,
+// gridDim.x = the workgroups that stay for it (what the device holds, shared evenly); workgroup b takes the groups
+// b, b + gridDim.x, ... of GROUP proposals of every half-step.  What a half-step needs from an earlier one comes from the
+// transient's own board of tagged rows (the sampler's k_solo_run board): a wave's head polls the rows its draw record
+// names, its commit posts the walker's new row.  No kernel boundary, the tables staged ONCE per launch -- and with them
+// the interpolants, which a launch per half-step reads from L2 point by point because staging 24 KiB more per workgroup
+// and half-step costs more than it saves.  A wave walks the units of ITS proposal only (u = wave mod GROUP), so beyond the
+// staging there is no barrier at all.  Same arithmetic, same reduction tree: the chains are bitwise k_pop's.
+constexpr int pop_run_waves(int group) { return group == 12 ? 6 : group == 10 ? 5 : 4; }   // waves per SIMD the build aims at
+template <int ND, int VARIANT, int GROUP, int MODEL = 0>
+__global__ __launch_bounds__(64 * GROUP, pop_run_waves(GROUP))
+void k_pop_run(const MultiItem* __restrict__ items, long long rel0, int n_hs, long long state_from, int store_chain, int launch_no,
+               int n_wg) {
+    // (n_wg = gridDim.x, except in the test of a launch whose workgroups are not all there: LCF_RUN_TEST_MISSING)
+    extern __shared__ __align__(16) unsigned char smem[];
+    typedef const MultiItem __attribute__((address_space(4)))* ItemPtr;
+    const ItemPtr itp = (ItemPtr)(items + blockIdx.y);
+    const MultiItem& it = *(const MultiItem*)itp;
+    const DevProblem& pb = it.pb;
+    const DevSampler& sm = it.sm;
+    constexpr int kThreads = 64 * GROUP;
+    const int nh = sm.n_half;
+    double* exptab = reinterpret_cast<double*>(smem);
+    double2* ltab = reinterpret_cast<double2*>(smem + kLdsHead * sizeof(double));
+    const FiltDesc* fdesc = reinterpret_cast<const FiltDesc*>(ltab + pb.n_lds_tab);
+    const int itab_at = pb.n_itab_lds > 0
+                            ? (int)(kLdsHead * sizeof(double) + (pb.n_lds_tab + kFdD2 * pb.n_filters) * sizeof(double2)) : -1;
+    double* scratch = reinterpret_cast<double*>(ltab + pb.stage_d2);       // [GROUP][kPopScratch]
+    double* red = scratch + GROUP * kPopScratch;                             // [GROUP][4 * kPopMaxParts] wave sums
+    constexpr int kD = ND > 0 ? ND : kMaxDim;
+    const int nd = ND > 0 ? ND : sm.n_dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long g_run0 = it.g_run0;
+    const unsigned int arrive_goal = it.arrive0 + (unsigned int)(launch_no + 1) * (unsigned int)n_wg;
+    const bool flip = it.flip != 0;
+    if (tid == 0) __hip_atomic_fetch_add(board_arrivals(sm), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rel0 == 0) {   // the transient's start state as version g_run0 of every row (whoever needs one polls for it)
+        const int col = tid & 31;
+        const double* X = flip ? sm.X_out : sm.X;
+        const double* LP = flip ? sm.LP_out : sm.LP;
+        const long long* nacc = flip ? sm.nacc_out : sm.nacc;
+        for (int w = blockIdx.x * (kThreads / 32) + tid / 32; w < sm.n_walkers; w += n_wg * (kThreads / 32))
+            if (col <= nd + 1) {
+                const double v = col < nd ? X[(size_t)w * nd + col] : col == nd ? LP[w] : (double)nacc[w];
+                board_post<true>(sm.board, sm, (unsigned int)g_run0, w, col, v);
+            }
+    }
+    stage_tables<VARIANT, true>(pb, exptab, ltab, 0., tid, kThreads);
+    if (it.itab_extra > 0) {   // the interpolants behind the image (DevProblem::n_itab_lds of this copy says they are there)
+        double2* dst = reinterpret_cast<double2*>(smem + itab_at);
+        const double2* src = reinterpret_cast<const double2*>(pb.itab);
+        for (int k = tid; k < it.itab_extra / 2; k += kThreads) dst[k] = src[k];
+    }
+    __syncthreads();
+    double* sc = scratch + wave * kPopScratch;
+    double* sq = sc + kNCoef + 2;
+    double* sx = sq + kMaxDim + (kMaxDim & 1);
+    const int n_groups = (nh + GROUP - 1) / GROUP;
+#pragma unroll 1
+    for (int h = 0; h < n_hs; ++h) {
+        const long long rel = rel0 + h, G = g_run0 + rel;
+        const DrawRec* draws = item_rows(it, rel);
+#pragma unroll 1
+        for (int grp = blockIdx.x; grp < n_groups; grp += n_wg) {
+            const int slot = grp * GROUP + wave;
+            DrawRec dr{-1, -1, -1, -1, 1., 0., 0., 0, 0};
+            if (slot < nh) dr = draws[slot];     // wave-uniform
+            if (dr.wid < 0) continue;            // (an odd ensemble's smaller colour leaves its last slot empty)
+            {
+                HeadRows<ND> rows;
+                head_fetch<ND, 2>(pb, sm, dr, lane, rows, G, g_run0, arrive_goal);
+                proposal_head<ND, 2, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
+            }
+            wave_lds_order();   // (lane 0 wrote coefficients, log-prior, proposal and row; every lane reads them)
+            // ---- the units of this wave's proposal: (part, v) = the 64 columns part_col0 + 64 v + lane, as in k_pop
+            const double lpr = sc[kNCoef];
+            if (lpr != -INFINITY) {
+                double cs[kNCoef];
+#pragma unroll
+                for (int k = 0; k < kNCoef; ++k) cs[k] = uniform_f64(sc[k]);
+#pragma unroll 1
+                for (int pv = 0; pv < pb.n_parts * 4; ++pv) {
+                    const int part = pv >> 2, v = pv & 3;
+                    double ws = 0.;
+                    const bool empty = part_entry(pb.part_col0, part) + 64 * v >= part_entry(pb.part_col0, part + 1);
+                    if (!empty) {
+                        const double term = epochs_loop<VARIANT, true, false, MODEL>(pb, part, sq, cs, ltab, fdesc, ExpTab{exptab},
+                                                                                     64 * v + lane, itab_at);
+                        ws = wave_sum(term);
+                    }
+                    if (lane == 0) red[(wave * kPopMaxParts + part) * 4 + v] = ws;
+                }
+            }
+            // ---- accept / reject; lanes 0 .. nd+1 post the walker's row (position, log-posterior, acceptance count)
+            wave_lds_order();   // (lane 0 wrote the sums)
+            double nlp = -INFINITY;
+            if (lpr != -INFINITY) {
+                double sum = pb.use_sigma ? 0. : pb.log_norm_const;   // fixed order: parts, each (w0 + w1) + (w2 + w3)
+                const double* r = red + wave * kPopMaxParts * 4;
+                for (int k = 0; k < pb.n_parts; ++k) sum += (r[4 * k] + r[4 * k + 1]) + (r[4 * k + 2] + r[4 * k + 3]);
+                nlp = lpr - 0.5 * sum;
+            }
+            const double lp_i = sx[kMaxDim];
+            const bool ok = (dr.zl + nlp - lp_i) > dr.lnu;   // emcee: (ndim - 1) ln z + lp_new - lp_old > ln u
+            const double count = sx[kMaxDim + 1] + (ok ? 1. : 0.);
+            if (lane <= nd + 1) {
+                double qv = 0., xv = 0.;
+#pragma unroll
+                for (int d = 0; d < kD; ++d)
+                    if (lane == d && d < nd) {
+                        qv = sq[d];
+                        xv = sx[d];
+                    }
+                const double v = lane < nd ? (ok ? qv : xv) : lane == nd ? (ok ? nlp : lp_i) : count;
+                board_post<true>(sm.board, sm, (unsigned int)(G + 1), dr.wid, lane, v);
+                if (rel >= state_from) {   // the run's last step: the state, into the set of buffers the run did not start from
+                    double* X = flip ? sm.X : sm.X_out;
+                    double* LP = flip ? sm.LP : sm.LP_out;
+                    long long* nacc = flip ? sm.nacc : sm.nacc_out;
+                    if (lane < nd) X[(size_t)dr.wid * nd + lane] = v;
+                    else if (lane == nd) LP[dr.wid] = v;
+                    else nacc[dr.wid] = (long long)v;
+                }
+                if (store_chain) {
+                    const long long row = rel / 2;
+                    if (lane < nd) sm.chain[((size_t)row * sm.n_walkers + dr.wid) * nd + lane] = v;
+                    else if (lane == nd) sm.chain_lp[(size_t)row * sm.n_walkers + dr.wid] = v;
+                }
+            }
+            if (lane == 0 && nlp != nlp) atomicOr(sm.err, 1);
+            wave_lds_order();   // (the next proposal's head overwrites what the lanes have just read)
+        }
     }
 }
 
@@ -3768,7 +3925,7 @@ lcf_status run_capacity(lcf_sampler* s, K kernel, int threads, size_t lds) {
 // sampler's first one-launch run is enqueued and again only when something in it has changed (a longer chain).  The
 // two sets of state buffers keep their places in it -- X / LP / nacc = the set the sampler was created with -- and the
 // launch's flags say which of them holds the run's start state.
-lcf_status run_image(lcf_sampler* s, hipStream_t st, const DevSampler** out, int* flags) {
+DevSampler run_struct(const lcf_sampler* s) {
     DevSampler rs = s->ds;
     const bool flip = s->run_flip;
     rs.X = flip ? s->alt_X : s->ds.X;
@@ -3785,6 +3942,22 @@ lcf_status run_image(lcf_sampler* s, hipStream_t st, const DevSampler** out, int
     rs.ring = kRunRing;
     rs.snap_out = reinterpret_cast<unsigned long long*>(s->snap);
     rs.snap_flags = s->snap_flags();
+    return rs;
+}
+
+// The buffers a sampler's resident launches need beside its own: the board of tagged rows and the second set of state.
+lcf_status run_buffers(lcf_sampler* s) {
+    if (s->run_board_mem) return LCF_OK;
+    if (lcf_status r = polled_alloc(s->e->device, false, s->run_board_bytes(), &s->run_board_mem)) return r;
+    const size_t nw = s->ds.n_walkers;
+    if (lcf_status r = dalloc(&s->alt_X, nw * s->ds.n_dim, s->owned)) return r;
+    if (lcf_status r = dalloc(&s->alt_LP, nw, s->owned)) return r;
+    return dalloc(&s->alt_nacc, nw, s->owned);
+}
+
+lcf_status run_image(lcf_sampler* s, hipStream_t st, const DevSampler** out, int* flags) {
+    const DevSampler rs = run_struct(s);
+    const bool flip = s->run_flip;
     if (!s->d_run_image) {
         LCF_HIP(hipMalloc((void**)&s->d_run_image, sizeof(DevSampler)));
         s->owned.push_back(s->d_run_image);
@@ -4105,6 +4278,46 @@ lcf_status sampler_begin(lcf_sampler* s, int64_t first_step, int64_t n_steps, in
     s->spec_first = -1;
     if (defer) return LCF_OK;
     return generate_block(s, 0, gen ? gen : e->stream);
+}
+
+// k_pop_run<ND, 1, G, M> for the population's shape: `L` null = its LDS attribute set and the workgroups a CU holds asked;
+// else the launch.
+struct PopRunLaunch {
+    dim3 grid;
+    hipStream_t st;
+    const MultiItem* items;
+    long long rel, state_from;
+    int n_hs, store_chain, launch_no, n_wg;
+};
+template <int ND, int G, int M>
+hipError_t pop_run_do(const PopRunLaunch* L, size_t lds, int* per_cu) {
+    const auto kernel = k_pop_run<ND, 1, G, M>;
+    if (!L) {
+        if (lds > 64 * 1024)
+            if (hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, 64 * G, lds);
+    }
+    hipLaunchKernelGGL(kernel, L->grid, dim3(64 * G), lds, L->st, L->items, L->rel, L->n_hs, L->state_from, L->store_chain,
+                       L->launch_no, L->n_wg);
+    return hipGetLastError();
+}
+template <int G>
+hipError_t pop_run_shape(int same_dim, int spec, const PopRunLaunch* L, size_t lds, int* per_cu) {
+    if (same_dim == 5 && spec == kShockCooling) return pop_run_do<5, G, kShockCooling>(L, lds, per_cu);
+#ifndef LCF_DEV_BUILD
+    if (same_dim == 4 && spec == kShockCooling2) return pop_run_do<4, G, kShockCooling2>(L, lds, per_cu);
+#endif
+    return pop_run_do<0, G, 0>(L, lds, per_cu);
+}
+hipError_t pop_run_kernel(int group, int same_dim, int spec, const PopRunLaunch* L, size_t lds, int* per_cu) {
+    switch (group) {
+#ifdef LCF_POP_GROUPS_ALL
+        case 4: return pop_run_shape<4>(same_dim, spec, L, lds, per_cu);
+        case 10: return pop_run_shape<10>(same_dim, spec, L, lds, per_cu);
+        case 12: return pop_run_shape<12>(same_dim, spec, L, lds, per_cu);
+#endif
+        default: return pop_run_shape<kPopRunGroup>(same_dim, spec, L, lds, per_cu);
+    }
 }
 
 }  // namespace
@@ -4788,13 +5001,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
     s->ds.inline_finalize = 1;  // single GPU: no separate finalize / accept launches
     LCF_HIP(hipEventRecord(s->ev0, st));
     if (one_launch) {   // the workgroups stay for a block of half-steps and hand each other rows (k_solo_run)
-        if (!s->run_board_mem) {
-            if (lcf_status r = polled_alloc(s->e->device, false, s->run_board_bytes(), &s->run_board_mem)) return r;
-            const size_t nw = s->ds.n_walkers;
-            if (lcf_status r = dalloc(&s->alt_X, nw * s->ds.n_dim, s->owned)) return r;
-            if (lcf_status r = dalloc(&s->alt_LP, nw, s->owned)) return r;
-            if (lcf_status r = dalloc(&s->alt_nacc, nw, s->owned)) return r;
-        }
+        if (lcf_status r = run_buffers(s)) return r;
         s->replay_first = first_step;
         s->replay_steps = n_steps;
         s->replay_split = split_mode;
@@ -4878,8 +5085,11 @@ lcf_status lcf_sampler_run(lcf_sampler* s, int64_t first_step, int64_t n_steps, 
 
 // Population mode: the same n_steps for `n` samplers (one transient each, same walker count) with ONE k_step and ONE
 // k_points launch per half-step covering all of them (blockIdx.y = transient).
-lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, int64_t n_steps, int32_t split_mode,
-                              int32_t store_chain, double* elapsed_ms) {
+// (`resident`: the transients' workgroups may stay for blocks of half-steps, k_pop_run; false = a launch per half-step,
+// what a run falls back to -- for the rest of the process -- after a resident launch whose workgroups were not all there)
+static bool g_pop_run_off = false;
+static lcf_status population_run(lcf_sampler** ss, int32_t n, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                                 int32_t store_chain, double* elapsed_ms, bool resident) {
     if (!ss || n <= 0) return fail(LCF_ERR_INVALID_ARGUMENT, "null argument");
     if (n > 65535) return fail(LCF_ERR_INVALID_ARGUMENT, "at most 65535 transients per call");
     if (split_mode == LCF_SPLIT_HOST) return fail(LCF_ERR_UNSUPPORTED, "population runs use identity or random splits");
@@ -5018,6 +5228,42 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     for (int t = 1; t < n; ++t)
         if (specialised_model(items[t].pb) != pop_spec) pop_spec = 0;
     LCF_HIP(hipSetDevice(s0->e->device));
+    // Resident form (k_pop_run): the workgroups stay for a block of half-steps and hand each other rows through the
+    // transients' boards.  The launch stages the interpolants in LDS as well, where the engine's image leaves them out.
+    const bool no_pop_run = std::getenv("LCF_NO_POP_RUN") != nullptr || std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
+    const bool pop_itab_lds = !(std::getenv("LCF_POP_ITAB_LDS") && std::atoi(std::getenv("LCF_POP_ITAB_LDS")) == 0);
+    resident = resident && one_launch && !no_pop_run && !g_pop_run_off && n_steps > 0 && run_claim(s0->e->device, pop_stream);
+    RunClaim claim{s0->e->device, pop_stream, resident};
+    size_t run_lds = 0;
+    int run_group = kPopRunGroup;   // proposals (= waves) per workgroup of the resident form
+#ifdef LCF_POP_GROUPS_ALL
+    if (const char* env = std::getenv("LCF_POP_GROUP")) run_group = std::atoi(env);   // (experiments: 4, 8, 10, 12)
+#endif
+    if (resident) {
+        for (int t = 0; t < n; ++t) {
+            lcf_sampler* s = ss[t];
+            if (lcf_status r = run_buffers(s)) {
+                hipFree(dgen);
+                return r;
+            }
+            MultiItem& it = items[t];
+            it.sm = run_struct(s);
+            it.g_run0 = g;
+            it.flip = s->run_flip ? 1 : 0;
+            it.itab_extra = 0;
+            it.arrive0 = s->run_arrivals;
+            it.pad = 0u;
+            DevProblem& ip = it.pb;
+            const size_t n_itab = ip.use_itab ? (size_t)ip.n_filters * ip.itab_m * 8 : 0;
+            if (pop_itab_lds && n_itab > 0 && ip.n_itab_lds == 0 && ip.n_spl_lds == 0 && n_itab * sizeof(double) <= 40 * 1024) {
+                it.itab_extra = (int)n_itab;
+                ip.n_itab_lds = (int)n_itab;
+                ip.stage_d2 += (int)(n_itab / 2);
+            }
+            run_lds = std::max(run_lds, kLdsHead * sizeof(double) + (size_t)ip.stage_d2 * sizeof(double2) +
+                                            (size_t)run_group * (kPopScratch + 4 * kPopMaxParts) * sizeof(double));
+        }
+    }
     MultiItem* ditems = nullptr;
     LCF_HIP(hipMalloc((void**)&ditems, (size_t)n * sizeof(MultiItem)));
     hipStream_t st = s0->e->stream;
@@ -5027,7 +5273,51 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
     if (err == hipSuccess) err = hipEventRecord(ev0, st);
     const dim3 gs((unsigned)nh, (unsigned)n), gp((unsigned)(nh * max_parts), (unsigned)n);
     const dim3 bs(64), bp(kBlock);
-    if (one_launch) {
+    int run_launches = 0, run_grid = 0;
+    if (resident) {
+        // gridDim.x workgroups per transient, all of them on the device at once: what the device holds, shared evenly --
+        // and no more than give every workgroup the same number of groups of proposals per half-step
+        const int n_groups = (nh + run_group - 1) / run_group;
+        int per_cu = 0;
+        err = pop_run_kernel(run_group, same_dim, pop_spec, nullptr, run_lds, &per_cu);
+        int cap = per_cu * s0->e->n_cus;
+        if (const char* env = std::getenv("LCF_RUN_GRID")) cap = std::min(cap, std::atoi(env));  // (tests)
+        const int chunk = std::min<int>(n, std::max(cap, 1));          // transients per launch
+        const int room = std::max(1, cap / chunk);
+        const int per_wg = (n_groups + std::min(room, n_groups) - 1) / std::min(room, n_groups);
+        run_grid = (n_groups + per_wg - 1) / per_wg;
+        if (cap < 1 && err == hipSuccess) err = hipErrorInvalidConfiguration;
+        const bool test_missing = std::getenv("LCF_RUN_TEST_MISSING") != nullptr;
+        const long long state_from = 2 * (long long)(n_steps - 1);
+        for (long long rel = 0; rel < 2 * n_steps && err == hipSuccess;) {
+            if (pop_enter(rel) != LCF_OK) err = hipErrorUnknown;
+            if (err != hipSuccess) break;
+            const int64_t b = s0->blk_current;
+            const long long end = 2 * (s0->block_start(b) + s0->block_len(b));
+            const int n_hs = (int)std::min<long long>(kRunSpan, end - rel);
+            for (int c0 = 0; c0 < n && err == hipSuccess; c0 += chunk) {
+                const int nc = std::min(chunk, n - c0);
+                const PopRunLaunch L{dim3((unsigned)(test_missing && run_grid > 1 ? run_grid - 1 : run_grid), (unsigned)nc), st,
+                                     ditems + c0, rel, state_from, n_hs, store_chain ? 1 : 0, run_launches, run_grid};
+                err = pop_run_kernel(run_group, same_dim, pop_spec, &L, run_lds, nullptr);
+            }
+            ++run_launches;
+            for (int t = 0; t < n; ++t)
+                if (st != ss[t]->e->stream) ss[t]->foreign_stream = true;
+            if (err == hipSuccess && pop_leave() != LCF_OK) err = hipErrorUnknown;
+            rel += n_hs;
+        }
+        for (int t = 0; t < n; ++t) {   // the state behind this run is in the other set of buffers now
+            lcf_sampler* s = ss[t];
+            s->run_arrivals += (unsigned int)(run_launches * run_grid);
+            std::swap(s->ds.X, s->alt_X);
+            std::swap(s->ds.LP, s->alt_LP);
+            std::swap(s->ds.nacc, s->alt_nacc);
+            s->run_flip = !s->run_flip;
+        }
+        claim.held = false;
+        run_release(s0->e->device, st);
+    } else if (one_launch) {
         const dim3 gq((unsigned)((nh + pop_group - 1) / pop_group), (unsigned)n), bq(64 * pop_group);
         for (int64_t k = 0; k < 2 * n_steps && err == hipSuccess; ++k) {
             if (pop_enter(k) != LCF_OK) err = hipErrorUnknown;
@@ -5056,7 +5346,7 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
             if (err == hipSuccess) err = hipGetLastError();
         }
     }
-    for (int64_t k = 0; !one_launch && k <= 2 * n_steps && err == hipSuccess; ++k) {
+    for (int64_t k = 0; !one_launch && !resident && k <= 2 * n_steps && err == hipSuccess; ++k) {
         const bool have_next = k < 2 * n_steps, have_prev = k > 0;
         if (!have_next && !have_prev) break;
         if (have_next && pop_enter(k) != LCF_OK) err = hipErrorUnknown;   // (every transient's block of draw records)
@@ -5115,11 +5405,55 @@ lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, i
         ss[t]->snap_valid = true;
         ss[t]->last_ms = ms;
         ss[t]->last_rows = false;
-        ss[t]->last_kernel = one_launch ? LCF_KERNEL_POPULATION : LCF_KERNEL_POPULATION_PHASES;
+        ss[t]->last_kernel = resident ? LCF_KERNEL_POPULATION_RUN : one_launch ? LCF_KERNEL_POPULATION : LCF_KERNEL_POPULATION_PHASES;
+        ss[t]->last_launches = resident ? run_launches : 2 * n_steps * (one_launch ? 1 : 2);
+    }
+    if (resident) {
+        // A resident launch whose workgroups were not all on the device (somebody else's resident kernel holds CUs) has
+        // given up within the bound of its waits.  No state has been written -- that goes into the other set of buffers,
+        // in the last step: take the states the run started from, drop what it reported, and run the same steps with a
+        // launch per half-step, as every later population run of this process.
+        bool gave_up = false;
+        for (int t = 0; t < n; ++t) {
+            int e = 0;
+            std::memcpy(&e, ss[t]->snap, sizeof(int));
+            const unsigned int* flags = ss[t]->snap_flags();
+            for (int k = 0; k < 2 * kSnapFlags; ++k) e |= (int)flags[k];
+            gave_up = gave_up || (e & 2);
+        }
+        if (gave_up) {
+            for (int t = 0; t < n; ++t) {
+                lcf_sampler* s = ss[t];
+                std::swap(s->ds.X, s->alt_X);
+                std::swap(s->ds.LP, s->alt_LP);
+                std::swap(s->ds.nacc, s->alt_nacc);
+                s->run_flip = !s->run_flip;
+                int sticky = 0;
+                std::memcpy(&sticky, s->snap, sizeof(int));
+                sticky &= 1;                                   // (a NaN of an earlier run stays reported)
+                LCF_HIP(hipMemcpy(s->ds.err, &sticky, sizeof(int), hipMemcpyHostToDevice));
+                std::memcpy(s->snap, &sticky, sizeof(int));
+                std::memset(s->snap_flags(), 0, 2 * kSnapFlags * sizeof(unsigned int));
+                LCF_HIP(hipMemset(static_cast<unsigned char*>(s->run_board_mem) + s->run_board_bytes() - kBoardClear * sizeof(unsigned int),
+                                  0, kBoardClear * sizeof(unsigned int)));
+                s->run_arrivals = 0;
+                invalidate_snapshot(s);
+            }
+            std::fprintf(stderr, "liblcf_hip: a resident population launch gave up waiting for a row: its workgroups were not all "
+                         "resident (another resident kernel on this GPU?); the steps are repeated with a launch per half-step, as are "
+                         "this process's later population runs (LCF_NO_POP_RUN=1 avoids the wait)\n");
+            g_pop_run_off = true;
+            return population_run(ss, n, first_step, n_steps, split_mode, store_chain, elapsed_ms, false);
+        }
     }
     for (int t = 0; t < n; ++t)
         if (lcf_status r = lcf_sampler_check(ss[t])) return r;
     return LCF_OK;
+}
+
+lcf_status lcf_population_run(lcf_sampler** ss, int32_t n, int64_t first_step, int64_t n_steps, int32_t split_mode,
+                              int32_t store_chain, double* elapsed_ms) {
+    return population_run(ss, n, first_step, n_steps, split_mode, store_chain, elapsed_ms, true);
 }
 
 lcf_status lcf_sampler_get_chain(lcf_sampler* s, double* chain, double* log_prob) {

@@ -459,7 +459,7 @@ class NativeSampler:
         """What executed the half-steps of the last run: 'phases' | 'fused' | 'solo' | 'run' (k_solo_run: resident
         workgroups, one launch per block of half-steps) | 'population' (one launch per half-step for all transients of
         a population) | 'population-phases' (None: no run yet)."""
-        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run'}.get(
+        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run', 6: 'population-run'}.get(
             self._lib.lcf_sampler_last_run_kernel(self._h))
 
     def last_run_launches(self):

@@ -415,10 +415,12 @@ def test_collective_none_probes_and_picks_a_driver_between_processes():
 
 @pytest.mark.parametrize('nwalkers', [21, 64])
 def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
-    """Population mode with shared epochs runs ONE launch per half-step for all transients (k_pop: a workgroup per four
-    proposals, accept test included).  Its chains are bitwise those of the two-launch path (LCF_NO_POP=1), and the
-    oracle-driven chain of a transient; 21 walkers = 11 slots per half-step: a partly filled last workgroup and, in
-    every second half-step, an empty slot."""
+    """Population mode with shared epochs: the transients' workgroups stay for blocks of half-steps and hand each other
+    rows through the transients' boards (k_pop_run), or -- LCF_NO_POP_RUN=1 -- ONE launch per half-step for all transients
+    (k_pop: a workgroup per four proposals, accept test included).  Their chains are bitwise those of the two-launch path
+    (LCF_NO_POP=1), and the oracle-driven chain of a transient; 21 walkers = 11 slots per half-step: a partly filled last
+    workgroup and, in every second half-step, an empty slot.  Resident launches also with blocks of 2 steps of draw
+    records (several launches per run) and with 2 workgroups per transient (several groups of proposals per workgroup)."""
     from lightcurve_fitting_amd.sampler import PopulationSampler
     problems, x0, pbs = [], {}, []
     for k in range(4):
@@ -435,18 +437,75 @@ def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
         problems.append((M.ShockCooling(redshift=0.), lc_dict(t, names, y, dy), priors))
         x0[k] = truth * (1 + 0.05 * rng.standard_normal((nwalkers, 5)))
     chains = {}
-    for no_pop in (False, True):
-        if no_pop:
-            monkeypatch.setenv('LCF_NO_POP', '1')
+    forms = {'population-run': {}, 'population': {'LCF_NO_POP_RUN': '1'}, 'population-phases': {'LCF_NO_POP': '1'},
+             'population-run, blocks of 2 steps': {'LCF_DRAW_BLOCK': '2'},
+             'population-run, 8 workgroups': {'LCF_RUN_GRID': '8'},
+             'population-run, interpolants from L2': {'LCF_POP_ITAB_LDS': '0'}}
+    for form, env in forms.items():
+        for name in ('LCF_NO_POP_RUN', 'LCF_NO_POP', 'LCF_DRAW_BLOCK', 'LCF_RUN_GRID', 'LCF_POP_ITAB_LDS'):
+            monkeypatch.delenv(name, raising=False)
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
         pop = PopulationSampler(problems, nwalkers, seed=17)
         pop.run_mcmc(x0, 6)
         pop.run_mcmc(None, 3)
-        assert pop[0]._native.last_run_kernel() == ('population-phases' if no_pop else 'population')
-        chains[no_pop] = [(pop[k].get_chain(), pop[k].get_log_prob(), pop[k].acceptance_fraction) for k in range(4)]
-    for a, b in zip(chains[False], chains[True]):
-        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+        assert pop[0]._native.last_run_kernel() == form.split(',')[0]
+        if 'blocks' in form:
+            assert pop[0]._native.last_run_launches() == 2
+        chains[form] = [(pop[k].get_chain(), pop[k].get_log_prob(), pop[k].acceptance_fraction) for k in range(4)]
+    for form in forms:
+        for a, b in zip(chains[form], chains['population-phases']):
+            assert all(np.array_equal(u, v) for u, v in zip(a, b)), form
     ref, ref_lp, _ = O.stretch_move_run(oracle_log_posterior(pbs[2]), x0[2], 9, 17 + 2)
-    assert relerr(chains[False][2][0], ref) < 1e-9 and relerr(chains[False][2][1], ref_lp) < 1e-9
+    assert relerr(chains['population-run'][2][0], ref) < 1e-9 and relerr(chains['population-run'][2][1], ref_lp) < 1e-9
+
+
+def test_population_resident_launch_that_is_not_all_there_falls_back(monkeypatch):
+    """A resident population launch one of whose workgroups never starts (LCF_RUN_TEST_MISSING: what another process's
+    resident kernel on the same GPU does to it) gives up within the residency bound, leaves the transients' states
+    untouched, and the same steps run with a launch per half-step: the same chains, well inside a second."""
+    import subprocess
+    import sys
+    import os
+    code = """
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+from lightcurve_fitting_amd import models as M
+from lightcurve_fitting_amd.sampler import PopulationSampler
+problems, x0 = [], {}
+for k in range(3):
+    rng = np.random.default_rng(900 + k)
+    epochs = np.sort(rng.uniform(0.4, 9., 50))
+    t, names = np.repeat(epochs, 6), list(np.tile(list('UBVgri'), 50))
+    truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    m = M.ShockCooling(redshift=0.)
+    y = m(t, names, *truth) * (1 + 0.05 * rng.standard_normal(len(t)))
+    problems.append((m, {'MJD': t, 'filter': names, 'lum': y, 'dlum': 0.05 * np.abs(y)},
+                     [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]))
+    x0[k] = truth * (1 + 0.05 * rng.standard_normal((32, 5)))
+os.environ['LCF_NO_POP_RUN'] = '1'
+ref = PopulationSampler(problems, 32, seed=5)
+ref.run_mcmc(x0, 5)
+del os.environ['LCF_NO_POP_RUN']
+os.environ['LCF_RUN_TEST_MISSING'] = '1'
+pop = PopulationSampler(problems, 32, seed=5)
+t0 = time.time()
+pop.run_mcmc(x0, 5)
+dt = time.time() - t0
+assert pop[0]._native.last_run_kernel() == 'population', pop[0]._native.last_run_kernel()
+for k in range(3):
+    assert np.array_equal(pop[k].get_chain(), ref[k].get_chain())
+    assert np.array_equal(pop[k].acceptance_fraction, ref[k].acceptance_fraction)
+del os.environ['LCF_RUN_TEST_MISSING']
+pop.run_mcmc(None, 2)      # (later population runs of the process: a launch per half-step)
+assert pop[0]._native.last_run_kernel() == 'population'
+print('OK %%.2f' %% dt)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith('OK'), (out.stdout[-1500:], out.stderr[-3000:])
+    assert float(out.stdout.split()[1]) < 1.0, out.stdout
+    assert 'resident population launch gave up' in out.stderr
 
 
 def test_row_boards_companion_shape():

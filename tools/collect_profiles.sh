@@ -15,8 +15,8 @@ mkdir -p $OUT $FINAL
 cd /tmp && export TMPDIR=/tmp
 FAILED=0
 declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
-declare -A PSTEPS=( [mcmc]=64 [companion]=2 [population]=3 [sed]=1 )   # (mcmc: two launches of 64 half-steps)
-declare -A KERNEL=( [mcmc]=k_solo_run [companion]=k_solo [population]=k_pop [sed]=k_sed_interp )
+declare -A PSTEPS=( [mcmc]=64 [companion]=2 [population]=144 [sed]=1 )   # (mcmc: two launches of 64 half-steps; population: 32 + 4 x 64)
+declare -A KERNEL=( [mcmc]=k_solo_run [companion]=k_solo [population]=k_pop_run [sed]=k_sed_interp )
 declare -A PTAG=( [mcmc]=k_solo_run_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )
 # (the profiled bench runs must stay ONE process each: the end-to-end block of the headline line starts a child)
 export LCF_BENCH_NO_E2E=1
@@ -38,20 +38,29 @@ import csv, glob, collections, json, re, sys
 out, w, kern, dst, commit, root = sys.argv[1:7]
 sys.path.insert(0, root)
 import bench
-res, name = {}, None
+res, name, timed, hs = {}, None, None, None
+# (a profiled run that prints a bench line with resident launches: only the launches of its TIMED steps are averaged --
+# the last 2 steps / half_steps_per_launch of them -- and the summary says how many half-steps such a launch covers)
+for log in sorted(glob.glob(out + f'/pmc_{w}_*.log')):
+    for ln in open(log, errors='replace'):
+        if ln.startswith('{') and '"half_steps_per_launch"' in ln:
+            d = json.loads(ln)
+            hs = d['roofline']['half_steps_per_launch']
+            timed = round(2 * d['steps'] / hs)
 for p in sorted(glob.glob(out + f'/pmc_{w}_*/*/*_counter_collection.csv')):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
+    for r in sorted(csv.DictReader(open(p)), key=lambda r: int(r['Dispatch_Id'])):
         if kern in r['Kernel_Name']:
             m = re.search(r'(k_\w+(<[^>]*>)?)', r['Kernel_Name'])
             name = m.group(1) if m else r['Kernel_Name'][:60]
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
+        v = v[-timed:] if timed else v
         res[k] = {'mean_per_launch': sum(v) / len(v), 'launches': len(v)}
 if not res:
     raise SystemExit(f'!! {w}: no counter rows for kernel {kern}: no summary written')
 json.dump({'workload': w, 'kernel': name, 'collected_at_commit': commit, 'kernel_source_sha256': bench.kernel_source_sha(),
-           'counters': res}, open(dst, 'w'), indent=1)
+           'half_steps_per_launch': hs, 'counters': res}, open(dst, 'w'), indent=1)
 print(w, name, {k: round(v['mean_per_launch'], 1) for k, v in res.items()})
 PY
   [ $? -eq 0 ] || FAILED=1
