@@ -1509,10 +1509,18 @@ __global__ __launch_bounds__(kBlock, LCF_WAVES) void k_fused(const DevProblem pb
 // most 3 kRunSpan + 2 versions behind anything another rank writes: kRing = 256 versions are never overrun.
 constexpr int kRing = 256;
 constexpr int kSnapFlags = 1024;
-// One-launch runs of ONE GPU (k_solo_run): a launch covers at most kRunSpan half-steps, reads versions >= G - 3 and
+// One-launch runs of ONE GPU (k_solo_run, k_pop_run): a launch covers at most kRunSpanSolo half-steps, reads versions >= G - 3 and
 // writes G + 1: kRunRing versions are never overrun however far the workgroups of a launch drift apart.
-constexpr int kRunRing = 128;
+// (Between ranks a launch covers at most kRunSpan half-steps -- the ring of the inter-rank boards bounds it, below; on one
+// GPU up to kRunSpanSolo: a launch's start-up -- staging, first fetch, every workgroup arriving, ~18 us at configs[1] --
+// is then paid once per 256 half-steps instead of once per 64: 5.41 -> 5.31 us per half-step over a 1000-step run.)
+#ifndef LCF_RUN_SPAN_SOLO
+#define LCF_RUN_SPAN_SOLO 256
+#endif
+constexpr int kRunSpanSolo = LCF_RUN_SPAN_SOLO;
+constexpr int kRunRing = 2 * kRunSpanSolo;
 constexpr int kRunSpan = 64;
+static_assert((kRunRing & (kRunRing - 1)) == 0 && kRunRing >= kRunSpanSolo + 8, "the ring of a one-launch run covers a launch");
 constexpr int kRunStoreChain = 1, kRunFlip = 2;   // k_solo_run's run_flags: the run stores its chain; its start state is in X_out / LP_out / nacc_out
 // 32-bit words behind the rows: progress per rank, abort, 4 x diagnosis, arrivals (workgroups of resident launches that
 // have started, counted up from launch to launch: a launch knows the count that says "all of mine are there")
@@ -2410,7 +2418,7 @@ __device__ __forceinline__ void wave_lds_order() {
 }
 
 // ---- population mode with RESIDENT workgroups ------------------------------------------------------------------------
-// k_pop's half-step in a loop over up to kRunSpan half-steps, as k_solo_run is k_solo's: gridDim.y = transient,
+// k_pop's half-step in a loop over up to kRunSpanSolo half-steps, as k_solo_run is k_solo's: gridDim.y = transient,
 // gridDim.x = the workgroups that stay for it (what the device holds, shared evenly); workgroup b takes the groups
 // b, b + gridDim.x, ... of GROUP proposals of every half-step.  What a half-step needs from an earlier one comes from the
 // transient's own board of tagged rows (the sampler's k_solo_run board): a wave's head polls the rows its draw record
@@ -2479,9 +2487,13 @@ void k_pop_run(const MultiItem* __restrict__ items, long long rel0, int n_hs, lo
             if (slot < nh) dr = draws[slot];     // wave-uniform
             if (dr.wid < 0) continue;            // (an odd ensemble's smaller colour leaves its last slot empty)
             {
+                // (the head is a latency chain that the proposal's points wait for; the waves it shares the SIMD with are
+                // mostly in their points: 22.73 -> 21.97 us per half-step at configs[4])
+                __builtin_amdgcn_s_setprio(2);
                 HeadRows<ND> rows;
                 head_fetch<ND, 2>(pb, sm, dr, lane, rows, G, g_run0, arrive_goal);
                 proposal_head<ND, 2, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
+                __builtin_amdgcn_s_setprio(0);
             }
             wave_lds_order();   // (lane 0 wrote coefficients, log-prior, proposal and row; every lane reads them)
             // ---- the units of this wave's proposal: (part, v) = the 64 columns part_col0 + 64 v + lane, as in k_pop
@@ -2505,6 +2517,7 @@ void k_pop_run(const MultiItem* __restrict__ items, long long rel0, int n_hs, lo
             }
             // ---- accept / reject; lanes 0 .. nd+1 post the walker's row (position, log-posterior, acceptance count)
             wave_lds_order();   // (lane 0 wrote the sums)
+            __builtin_amdgcn_s_setprio(3);   // (the row's readers wait for this: 23.05 -> 22.70 us per half-step at configs[4])
             double nlp = -INFINITY;
             if (lpr != -INFINITY) {
                 double sum = pb.use_sigma ? 0. : pb.log_norm_const;   // fixed order: parts, each (w0 + w1) + (w2 + w3)
@@ -2540,6 +2553,7 @@ void k_pop_run(const MultiItem* __restrict__ items, long long rel0, int n_hs, lo
                 }
             }
             if (lane == 0 && nlp != nlp) atomicOr(sm.err, 1);
+            __builtin_amdgcn_s_setprio(0);
             wave_lds_order();   // (the next proposal's head overwrites what the lanes have just read)
         }
     }
@@ -3580,6 +3594,10 @@ lcf_status generate_block(lcf_sampler* s, int64_t b, hipStream_t consumer) {
 // A run usually continues where the last one stopped (burn-in -> sampling; run_mcmc(None, ...) in a loop).  Behind the
 // last launch of a run, generate the first block of such a continuation, so that its first half-step finds its draw
 // records ready: sampler_begin adopts them when the new run matches (first step, split mode, slot bookkeeping).
+// (Measured and dropped: the same BESIDE a one-block run instead of behind it -- into the other buffer, on a stream of the
+// sampler's own, of the lowest priority, enqueued before or after the run's launch -- so that the caller's
+// synchronisation does not wait for it.  The 20 us it takes behind the run disappear, but the resident launch beside it
+// takes 16-36 us longer -- its workgroups arrive later: 14.4-15.0 against 14.2 us per step of a 20-step run.)
 lcf_status speculate_continuation(lcf_sampler* s, hipStream_t st) {
     s->spec_first = -1;
     if (s->pending || s->split_mode == LCF_SPLIT_HOST || s->run_steps == 0) return LCF_OK;
@@ -5013,7 +5031,7 @@ lcf_status lcf_sampler_run_async(lcf_sampler* s, int64_t first_step, int64_t n_s
             if (lcf_status r = enter_half_step(s, rel, st)) return r;
             const int64_t b = s->blk_current;
             const long long end = 2 * (s->block_start(b) + s->block_len(b));
-            const int n = (int)std::min<long long>(kRunSpan, end - rel);
+            const int n = (int)std::min<long long>(kRunSpanSolo, end - rel);
             if (lcf_status r = launch_run(s, rel, n, st)) return r;
             if (lcf_status r = leave_half_step(s, st)) return r;
             rel += n;
@@ -5294,7 +5312,7 @@ static lcf_status population_run(lcf_sampler** ss, int32_t n, int64_t first_step
             if (err != hipSuccess) break;
             const int64_t b = s0->blk_current;
             const long long end = 2 * (s0->block_start(b) + s0->block_len(b));
-            const int n_hs = (int)std::min<long long>(kRunSpan, end - rel);
+            const int n_hs = (int)std::min<long long>(kRunSpanSolo, end - rel);
             for (int c0 = 0; c0 < n && err == hipSuccess; c0 += chunk) {
                 const int nc = std::min(chunk, n - c0);
                 const PopRunLaunch L{dim3((unsigned)(test_missing && run_grid > 1 ? run_grid - 1 : run_grid), (unsigned)nc), st,
