@@ -2494,6 +2494,9 @@ void k_pop_run(const MultiItem* __restrict__ items, long long rel0, int n_hs, lo
                 head_fetch<ND, 2>(pb, sm, dr, lane, rows, G, g_run0, arrive_goal);
                 proposal_head<ND, 2, MODEL>(pb, sm, dr, lane, sc, sq, sx, rows);
                 __builtin_amdgcn_s_setprio(0);
+                // (Measured and dropped: the rows of the wave's NEXT proposal requested here and looked at when its head
+                // starts -- 23.6 against 21.9 us per half-step: loads return in order, so the first loads of the points
+                // wait for that round trip past the caches, and the request costs registers.)
             }
             wave_lds_order();   // (lane 0 wrote coefficients, log-prior, proposal and row; every lane reads them)
             // ---- the units of this wave's proposal: (part, v) = the 64 columns part_col0 + 64 v + lane, as in k_pop

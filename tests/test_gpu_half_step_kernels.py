@@ -460,6 +460,36 @@ def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
     assert relerr(chains['population-run'][2][0], ref) < 1e-9 and relerr(chains['population-run'][2][1], ref_lp) < 1e-9
 
 
+def test_population_resident_runs_mix_with_single_runs(monkeypatch):
+    """A transient's sampler shares its board of tagged rows, its second set of state buffers and its count of started
+    workgroups between the population's resident launches (k_pop_run) and its own (k_solo_run): population run ->
+    every ensemble on its own stream -> population run again gives the chains of three population runs with a launch per
+    half-step."""
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    problems, x0 = [], {}
+    for k in range(3):
+        rng = np.random.default_rng(700 + k)
+        epochs = np.sort(rng.uniform(0.4, 9., 40 + 9 * k))
+        t, names = np.repeat(epochs, 6), list(np.tile(list('UBVgri'), len(epochs)))
+        truth = np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+        m = M.ShockCooling(redshift=0.)
+        y = m(t, names, *truth) * (1 + 0.05 * rng.standard_normal(len(t)))
+        problems.append((m, lc_dict(t, names, y, 0.05 * np.abs(y)), [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]))
+        x0[k] = truth * (1 + 0.05 * rng.standard_normal((34, 5)))
+    out = {}
+    for form in ('mixed', 'reference'):
+        if form == 'reference':
+            monkeypatch.setenv('LCF_NO_POP_RUN', '1')
+        pop = PopulationSampler(problems, 34, seed=23)
+        pop.run_mcmc(x0, 5)
+        pop.run_mcmc(None, 4, batched=(form == 'reference'))
+        pop.run_mcmc(None, 3)
+        assert pop[0]._native.last_run_kernel() == ('population' if form == 'reference' else 'population-run')
+        out[form] = [(pop[k].get_chain(), pop[k].get_log_prob(), pop[k].acceptance_fraction) for k in range(3)]
+    for a, b in zip(out['mixed'], out['reference']):
+        assert a[0].shape[0] == 12 and all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
 def test_population_resident_launch_that_is_not_all_there_falls_back(monkeypatch):
     """A resident population launch one of whose workgroups never starts (LCF_RUN_TEST_MISSING: what another process's
     resident kernel on the same GPU does to it) gives up within the residency bound, leaves the transients' states
