@@ -586,7 +586,7 @@ def run_mcmc(args):
         pmc_tag = 'k_solo_run_mcmc' if (used, args.variant) == ('run', 3) else f'k_{used}_v{args.variant}_mcmc'
         roof = roofline_block(name, kern_ms, round((per_rank // 2) * hs_per_launch), quads, None, PEAK_FP64_TINSTR, ALG_INSTR,
                               ALG_BYTES, pmc_tag, waves_per_launch=(per_rank // 2) * 8,
-                              interp=(n_interp, N_EPOCHS) if n_interp else None)
+                              interp=(n_interp, N_EPOCHS) if n_interp else None, hs_per_launch=hs_per_launch)
         roof['half_steps_per_launch'] = hs_per_launch
         roof['kernel_ms_per_half_step'] = kern_ms / hs_per_launch
         if world > 1 and measured_in_the_run:

@@ -1593,6 +1593,12 @@ __device__ inline void board_abort(const DevSampler& sm, unsigned int what, unsi
 // started.  Rows of a launch whose workgroups are all resident arrive within microseconds; a wait that has lasted
 // DevSampler::resident_ticks (50 ms) looks at the word ONCE: all there -> keep waiting (a stalled peer rank, a busy
 // device); not all there -> the launch cannot make progress (another resident kernel holds the CUs): give up now.
+// (Measured and dropped, round 4: FOUR loads of the entry kept in flight a quarter of a round trip apart, each looked at
+// when it returns -- finer sampling than one look per round trip, but whoever finds its row must still wait for the other
+// three loads before their registers may be used again: 5.71 against 5.31 us per half-step at configs[1].  And the upper
+// bound of a head computed AHEAD of the partner's commit -- a second wave computes it from stale rows while the first one
+// polls, wrong chain, timing only: 5.13 against 5.31 us; with the two candidate heads, the second post and the second
+// poll a real version needs, nothing would be left of the 0.19.)
 template <bool AGENT = false>
 __device__ inline double board_take(const DevSampler& sm, unsigned int tag, int wid, int col, unsigned int arrive_goal = 0u) {
     const unsigned long long* p = board_entry(sm.board, sm, tag, wid, col);

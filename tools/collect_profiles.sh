@@ -14,7 +14,7 @@ rm -rf $OUT/trace_* $OUT/pmc_* $FINAL
 mkdir -p $OUT $FINAL
 cd /tmp && export TMPDIR=/tmp
 FAILED=0
-declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=300 [sed]=200 )
+declare -A STEPS=( [mcmc]=1000 [companion]=30 [population]=1000 [sed]=200 )
 declare -A PSTEPS=( [mcmc]=64 [companion]=2 [population]=144 [sed]=1 )   # (mcmc: two launches of 64 half-steps; population: 32 + 4 x 64)
 declare -A KERNEL=( [mcmc]=k_solo_run [companion]=k_solo [population]=k_pop_run [sed]=k_sed_interp )
 declare -A PTAG=( [mcmc]=k_solo_run_mcmc [companion]=k_solo_companion [population]=population [sed]=k_sed )

@@ -26,8 +26,11 @@ def main():
         s = NativeSampler(eng, bench.WALKERS_PER_GPU, bench.SEED + 7)
         s.set_state(bench.initial_walkers(bench.WALKERS_PER_GPU))
         s.run(0, steps, 'random', False)
+        # (`steps` and `roofline.half_steps_per_launch`: what tools/collect_profiles.sh reads to average the right launches
+        # and to say how many half-steps a profiled launch covered)
         print(json.dumps({'workload': workload, 'kernel': s.set_half_step_kernel('auto'), 'launches': s.last_run_launches(),
-                          'kernel_ms': s.last_run_ms() / s.last_run_launches()}))
+                          'kernel_ms': s.last_run_ms() / s.last_run_launches(), 'steps': steps,
+                          'roofline': {'half_steps_per_launch': 2. * steps / s.last_run_launches()}}))
     elif workload == 'companion':
         model, lc, priors, _ = bench.build_companion(0)
         eng = model.engine_for(lc, priors=priors)
