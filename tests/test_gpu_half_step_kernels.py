@@ -460,6 +460,40 @@ def test_population_one_launch_per_half_step(nwalkers, monkeypatch):
     assert relerr(chains['population-run'][2][0], ref) < 1e-9 and relerr(chains['population-run'][2][1], ref_lp) < 1e-9
 
 
+@pytest.mark.parametrize('shape', ['ShockCooling2', 'ShockCooling2 + sigma', 'ShockCooling + sigma'])
+def test_population_resident_other_models(shape, monkeypatch):
+    """k_pop_run for the other model-specialised kernel (ShockCooling2, four parameters) and for the generic one (a fitted
+    sigma: walker dimension at run time), odd ensembles, three and four filters: the chains of the two-launch path."""
+    from lightcurve_fitting_amd.sampler import PopulationSampler
+    two, sigma = shape.startswith('ShockCooling2'), shape.endswith('sigma')
+    truth = np.array([30., 3., 30., 0.2]) if two else np.array([1.2, 0.5, 3.0, 2.0, 0.1])
+    pri = ([M.UniformPrior(0., 100.)] * 3 + [M.UniformPrior(-1., 0.29)]) if two else \
+        ([M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.29)])
+    if sigma:
+        pri = pri + [M.UniformPrior(0., 5.)]
+    problems, x0 = [], {}
+    for k in range(3):
+        rng = np.random.default_rng(800 + k)
+        filts = list('BVgr')[:3 + k % 2]
+        epochs = np.sort(rng.uniform(0.4, 20., 30 + 17 * k))
+        t, names = np.repeat(epochs, len(filts)), list(np.tile(filts, len(epochs)))
+        m = M.ShockCooling2(redshift=0.01) if two else M.ShockCooling(redshift=0.01)
+        y = m(t, names, *truth) * (1 + 0.05 * rng.standard_normal(len(t)))
+        problems.append((m, lc_dict(t, names, y, 0.05 * np.abs(y)), pri) + (({'use_sigma': True},) if sigma else ()))
+        x0[k] = np.concatenate([truth, [0.5]] if sigma else [truth]) * (1 + 0.03 * rng.standard_normal((27, len(pri))))
+    out = {}
+    for form in ('population-run', 'population-phases'):
+        if form == 'population-phases':
+            monkeypatch.setenv('LCF_NO_POP', '1')
+        pop = PopulationSampler(problems, 27, seed=41)
+        pop.run_mcmc(x0, 7)
+        pop.run_mcmc(None, 2)
+        assert pop[0]._native.last_run_kernel() == form
+        out[form] = [(pop[k].get_chain(), pop[k].get_log_prob(), pop[k].acceptance_fraction) for k in range(3)]
+    for a, b in zip(out['population-run'], out['population-phases']):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
 def test_population_resident_runs_mix_with_single_runs(monkeypatch):
     """A transient's sampler shares its board of tagged rows, its second set of state buffers and its count of started
     workgroups between the population's resident launches (k_pop_run) and its own (k_solo_run): population run ->
