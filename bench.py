@@ -444,8 +444,8 @@ def half_step_kernel_ms(engine, nwalkers, x0, seed, reps=992):
     """(average duration of ONE LAUNCH of the half-step kernel of a single-GPU run in ms, which kernel, half-steps per
     launch), from HIP events on the engine's stream around `reps` steps of back-to-back launches (the draw-record kernels
     in between: 30 us per 256 steps).  k_solo / k_fused: one launch = one half-step = nwalkers/2 proposals (proposal +
-    thermal states + likelihood + accept test).  k_solo_run ('run'): the workgroups stay for a block of steps -- with
-    `reps` a multiple of 32 every launch covers exactly 32 steps = 64 half-steps."""
+    thermal states + likelihood + accept test).  k_solo_run ('run'): the workgroups stay for a block of up to 128 steps
+    (the first block of a run's draw records has 32 steps, the later ones 256: launches of 64 and 256 half-steps)."""
     from lightcurve_fitting_amd.engine import NativeSampler
     s = NativeSampler(engine, nwalkers, seed)
     used = s.set_half_step_kernel('auto')
@@ -862,7 +862,7 @@ def run_population(args):
                                      'transients of this GPU; the likelihood launch dominates)'}[used]
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
         launches = pop[pop.indices[0]]._native.last_run_launches() if used == 'population-run' else 2 * args.steps
-        hs_per_launch = 2 * args.steps / launches       # (resident launches: blocks of up to 64 half-steps)
+        hs_per_launch = 2 * args.steps / launches       # (resident launches: blocks of up to 256 half-steps)
         roof = roofline_block(name, pair_ms * hs_per_launch, int(32 * nw // 2 * hs_per_launch), quads, None, PEAK_FP64_TINSTR,
                               alg_instr, ALG_BYTES,
                               'population' if (used, args.variant) == ('population-run', 3) else f'{used}_v{args.variant}',

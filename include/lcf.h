@@ -221,7 +221,7 @@ int32_t lcf_sampler_one_launch(const lcf_sampler* s);
 /* Which kernels a single-GPU run (lcf_sampler_run / _run_async) may use for a half-step.  All of them produce the
  * same chain bit for bit; the choice exists for tests and measurements.
  *   AUTO:   one workgroup per proposal that also accepts / rejects, resident for a whole block of half-steps
- *           (k_solo_run: ONE launch per up to 32 steps (64 half-steps), rows handed from workgroup to workgroup through a board of
+ *           (k_solo_run: ONE launch per up to 128 steps (256 half-steps), rows handed from workgroup to workgroup through a board of
  *           tagged rows in device memory) where a proposal's parts fit one workgroup; else one workgroup per
  *           (proposal, part) and launch (k_fused); else proposal + likelihood launches
  *   SOLO:   as AUTO, but one launch per half-step (k_solo)
@@ -233,14 +233,15 @@ enum { LCF_HALF_STEP_AUTO = 0, LCF_HALF_STEP_FUSED = 1, LCF_HALF_STEP_PHASES = 2
 lcf_status lcf_sampler_set_half_step_kernel(lcf_sampler* s, int32_t choice, int32_t* used);
 
 /* What the half-steps of the sampler's last run were executed by (-1: no run yet): separate proposal / likelihood
- * launches, k_fused, k_solo; for lcf_population_run one launch per half-step for all transients (k_pop: a workgroup per
- * four proposals, accept test included) or the two launches k_step_multi + k_points_multi. */
+ * launches, k_fused, k_solo; for lcf_population_run resident workgroups for all transients (k_pop_run), one launch per
+ * half-step for all transients (k_pop: a workgroup per four proposals, accept test included) or the two launches
+ * k_step_multi + k_points_multi. */
 enum { LCF_KERNEL_PHASES = 0, LCF_KERNEL_FUSED = 1, LCF_KERNEL_SOLO = 2, LCF_KERNEL_POPULATION = 3,
        LCF_KERNEL_POPULATION_PHASES = 4, LCF_KERNEL_RUN = 5 /* k_solo_run: a block of half-steps per launch */,
        LCF_KERNEL_POPULATION_RUN = 6 /* k_pop_run: the same for all transients of a population */ };
 int32_t lcf_sampler_last_run_kernel(const lcf_sampler* s);
 /* Launches of that kernel in the last single-GPU run (lcf_sampler_run / _run_async): two per step, or -- k_solo_run --
- * one per block of up to 32 steps. */
+ * one per block of up to 128 steps (between ranks: 32); lcf_population_run: launches per run of the kernel it took. */
 int64_t lcf_sampler_last_run_launches(const lcf_sampler* s);
 
 /* Multi-GPU building blocks: one half-step split into phases so that the caller can all-gather the shard's new
