@@ -18,7 +18,7 @@ def wrap(name):
     def timed(*a, **k):
         t = time.perf_counter(); r = orig(*a, **k); spent[name] = spent.get(name, 0.) + time.perf_counter() - t; return r
     setattr(nat, name, timed)
-for name in ('run', 'naccepted', 'get_state'):
+for name in ('run', 'snapshot'):
     wrap(name)
 for i in range(8):
     spent.clear()
@@ -28,5 +28,5 @@ for i in range(8):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print('wall %.0f us | run_mcmc %.0f | native run %.0f, naccepted %.0f, get_state %.0f | device %.0f' %
-          (1e6 * (t2 - t0), 1e6 * (t1 - t0), 1e6 * spent['run'], 1e6 * spent['naccepted'], 1e6 * spent['get_state'], 1e3 * s.last_run_ms))
+    print('wall %.0f us | run_mcmc %.0f | native run %.0f, snapshot %.0f | device %.0f' %
+          (1e6 * (t2 - t0), 1e6 * (t1 - t0), 1e6 * spent['run'], 1e6 * spent.get('snapshot', 0.), 1e3 * s.last_run_ms))
