@@ -4848,12 +4848,16 @@ lcf_status lcf_sampler_run_peers(lcf_sampler* s, int64_t first_step, int64_t n_s
 namespace {
 // Row-board runs with RESIDENT workgroups (k_solo_run<..., RANKS>): where a single-GPU run of the rank's share would
 // take resident workgroups (run_eligible), and for the same reasons.  LCF_ROWS_PER_HALF_STEP=1: never.
+// (Light curves of more than two parts: up to TWO slots per workgroup -- a rank of a 2-GPU run of configs[2] has 1024
+// proposals: 36.1 us per half-step resident against 39.8 with a launch per half-step, whose row collection comes per
+// half-step as well; on one GPU the two forms are level at that size, 36.6 / 36.5, and the hardware's dispatch of a
+// workgroup per proposal wins beyond it.)
 bool rows_resident_eligible(const lcf_sampler* s, int width) {
     const bool disabled = std::getenv("LCF_NO_RUN_KERNEL") != nullptr || std::getenv("LCF_ROWS_PER_HALF_STEP") != nullptr;
     const bool any_size = std::getenv("LCF_RUN_ANY_SIZE") != nullptr;
     return !disabled && s->half_step_kernel == LCF_HALF_STEP_AUTO && solo_eligible(s) &&
            ((s->e->dp.n_parts <= 2 ? width <= 4 * kRunSlots
-                                   : (width > s->e->n_cus || (wide_runs() && run_wide(s, width))) && width <= kRunSlots) || any_size);
+                                   : (width > s->e->n_cus || (wide_runs() && run_wide(s, width))) && width <= 2 * kRunSlots) || any_size);
 }
 
 lcf_status board_alloc(lcf_sampler* s) {

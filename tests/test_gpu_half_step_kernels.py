@@ -620,6 +620,42 @@ def test_row_boards_companion_shape():
             assert np.array_equal(s.naccepted(), ref.naccepted())
 
 
+def test_row_boards_companion_several_slots_per_workgroup(monkeypatch):
+    """Ranks whose share exceeds one proposal per CU (configs[2] on two GPUs: 1024 proposals per rank) take the resident
+    form with 512-thread workgroups (k_solo_run<8, 1, true, 4, 0, RANKS>) and several slots of a half-step per workgroup:
+    two emulated ranks of 260 proposals each on 100 workgroups each, the chain of the single-GPU run bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    model, lc, priors, _ = bench.build_companion(0)
+    nwalkers, nsteps = 1040, 3
+    x0 = bench.companion_walkers(nwalkers)
+    ref = NativeSampler(model.engine_for(lc, priors=priors), nwalkers, 9)
+    assert ref.set_half_step_kernel('solo') == 'solo'
+    ref.set_state(x0)
+    ref.run(0, nsteps, 'random', True)
+    want_chain, want_lp = ref.get_chain()
+    monkeypatch.setenv('LCF_RUN_GRID', '100')
+    engines = [bench.build_companion(0)[0].engine_for(lc, priors=priors) for _ in range(2)]
+    samplers = [NativeSampler(e, nwalkers, 9) for e in engines]
+    ptrs = [s.board_export()[1] for s in samplers]
+    for r, s in enumerate(samplers):
+        s.board_connect(2, r, local_ptrs=ptrs)
+        s.set_state(x0)
+        s.run(100, nsteps, 'random', True)
+        s.set_state(x0)
+    for s in samplers:
+        s.run_rows(0, nsteps, 'random', True, asynchronous=True)
+    for s in samplers:
+        s.wait()
+        assert s.last_run_kernel() == 'run' and s.last_run_launches() == 1
+    for s in samplers:
+        chain, lp = s.get_chain()
+        assert np.array_equal(chain, want_chain) and np.array_equal(lp, want_lp)
+        assert np.array_equal(s.naccepted(), ref.naccepted())
+
+
 @pytest.mark.parametrize('form', ['resident', 'per half-step'])
 def test_row_boards_missing_rank_ends_with_an_error(monkeypatch, form):
     """A rank that never runs: the waits of the other one are bounded (LCF_PEER_WAIT_S, here 0.5 s; 5 s by default), the
