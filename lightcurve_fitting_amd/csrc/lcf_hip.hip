@@ -5263,7 +5263,17 @@ static lcf_status population_run(lcf_sampler** ss, int32_t n, int64_t first_step
     // transients' boards.  The launch stages the interpolants in LDS as well, where the engine's image leaves them out.
     const bool no_pop_run = std::getenv("LCF_NO_POP_RUN") != nullptr || std::getenv("LCF_NO_RUN_KERNEL") != nullptr;
     const bool pop_itab_lds = !(std::getenv("LCF_POP_ITAB_LDS") && std::atoi(std::getenv("LCF_POP_ITAB_LDS")) == 0);
-    resident = resident && one_launch && !no_pop_run && !g_pop_run_off && n_steps > 0 && run_claim(s0->e->device, pop_stream);
+    resident = resident && one_launch && !no_pop_run && !g_pop_run_off && n_steps > 0;
+    if (resident) {
+        // (a board of tagged rows and a second set of state buffers per transient -- 64 KB per walker: a population of
+        // thousands of transients stays with a launch per half-step rather than take more than half of the free memory)
+        size_t need = 0, free_b = 0, total_b = 0;
+        for (int t = 0; t < n; ++t)
+            if (!ss[t]->run_board_mem) need += ss[t]->run_board_bytes() + (size_t)ss[t]->ds.n_walkers * (ss[t]->ds.n_dim + 2) * 8;
+        if (need > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 2)) resident = false;
+        (void)hipGetLastError();
+    }
+    resident = resident && run_claim(s0->e->device, pop_stream);
     RunClaim claim{s0->e->device, pop_stream, resident};
     size_t run_lds = 0;
     int run_group = kPopRunGroup;   // proposals (= waves) per workgroup of the resident form
