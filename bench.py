@@ -857,7 +857,8 @@ def run_population(args):
                               'four proposals, serial heads side by side, accept test included)',
                 'population-run': 'k_pop_run<5,1,4> (the workgroups of all 32 transients of this GPU stay for blocks of up to 64 '
                                   'half-steps: 4 proposals at a time each, rows handed over through the transients\' boards of '
-                                  'tagged rows, tables and interpolants staged in LDS once per launch; time per HALF-STEP)',
+                                  'tagged rows, tables and interpolants staged in LDS once per launch; kernel_ms = one launch, '
+                                  'kernel_ms_per_half_step = one half-step of all transients)',
                 'population-phases': 'k_step_multi + k_points_multi (the two launches of a half-step of all 32 '
                                      'transients of this GPU; the likelihood launch dominates)'}[used]
         alg_instr = ALG_INSTR_PER_SAMPLE * int(eng.samples_per_eval) + ALG_INSTR_PER_POINT * 600
