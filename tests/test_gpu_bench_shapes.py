@@ -106,8 +106,8 @@ def test_config2_chain_at_the_benchmark_shape():
 
 
 def test_config4_population_at_the_benchmark_shape():
-    """32 transients x 512 walkers in lock step (one proposal launch + one likelihood launch per half-step for all of
-    them) == 32 independent single-transient runs, the same walker positions bit for bit; three of the transients against the oracle chain."""
+    """32 transients x 512 walkers in lock step (resident workgroups for all of them: k_pop_run) == 32 independent
+    single-transient runs, the same walker positions bit for bit; three of the transients against the oracle chain."""
     from lightcurve_fitting_amd import models as M
     rng = np.random.default_rng(bench.SEED + 5)
     priors = [M.UniformPrior(0., 10.)] * 4 + [M.UniformPrior(-1., 0.5)]
@@ -123,6 +123,7 @@ def test_config4_population_at_the_benchmark_shape():
         x0[k] = truth * rng.uniform(0.9, 1.1, (512, 5))
     pop = PopulationSampler(problems, 512, seed=77)
     pop.run_mcmc(x0, 3)
+    assert pop[0]._native.last_run_kernel() == 'population-run'
     orc = O.ShockCoolingOracle(0., 1.5)
     for k in range(32):
         model, lc, pri = problems[k]
