@@ -322,6 +322,10 @@ class Engine:
         return out
 
 
+#: `lcf_sampler_last_run_kernel` values (include/lcf.h: LCF_KERNEL_*) -> the names `last_run_kernel()` returns
+KERNEL_NAMES = {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run', 6: 'population-run'}
+
+
 class NativeSampler:
     """Thin handle on ``lcf_sampler`` (device-resident stretch move)."""
 
@@ -458,9 +462,9 @@ class NativeSampler:
     def last_run_kernel(self):
         """What executed the half-steps of the last run: 'phases' | 'fused' | 'solo' | 'run' (k_solo_run: resident
         workgroups, one launch per block of half-steps) | 'population' (one launch per half-step for all transients of
-        a population) | 'population-phases' (None: no run yet)."""
-        return {0: 'phases', 1: 'fused', 2: 'solo', 3: 'population', 4: 'population-phases', 5: 'run', 6: 'population-run'}.get(
-            self._lib.lcf_sampler_last_run_kernel(self._h))
+        a population) | 'population-run' (k_pop_run: resident workgroups for all transients) | 'population-phases'
+        (None: no run yet)."""
+        return KERNEL_NAMES.get(self._lib.lcf_sampler_last_run_kernel(self._h))
 
     def last_run_launches(self):
         """Launches of the half-step kernel in the last single-GPU run (two per step; 'run': one per block of steps)."""

@@ -387,3 +387,12 @@ def test_shipped_table_levels_are_the_built_ones_and_make_packing_cheap(monkeypa
     t0 = time.perf_counter()
     F.PackedTables(list('UBVgri'), z=0.012)
     assert time.perf_counter() - t0 < 0.05
+
+
+def test_kernel_names_follow_the_header():
+    """`NativeSampler.last_run_kernel()` names every LCF_KERNEL_* value of include/lcf.h, with the header's numbers."""
+    import re
+    from lightcurve_fitting_amd import engine
+    text = open(os.path.join(ROOT, 'include', 'lcf.h')).read()
+    values = {name.lower().replace('_', '-'): int(v) for name, v in re.findall(r'LCF_KERNEL_(\w+)\s*=\s*(\d+)', text)}
+    assert len(values) == 7 and values == {name: v for v, name in engine.KERNEL_NAMES.items()}
